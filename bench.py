@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path on BASELINE.json's metric/config.
+
+One "step" = one pass of the hot path over one batch: every chain of this rank gets its model
+spectrum, tempered log-likelihood AND gradient (setup -> eval -> finalize -> backward kernels) with
+params already resident in HBM.  Workload: config C2 of BASELINE.json -- model_MS_Global_a1etaa3_
+HarveyLike (id 2), 1e5 bins, 64 chains per GPU (weak scaling: N GPUs carry 64*N chains of one
+temperature ladder; the evaluation itself needs no collective).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (tamcmc_eval_kernel): algorithmic bytes (16 B x Nx x chains per
+                  launch) / its mean duration from HIP events on the launch stream, against 8 TB/s.
+                  The kernel is fp64-VALU bound, not HBM bound; "valu_frac" says how
+                  close it is to the roof that actually binds.
+  cpu_baseline -- the CPU oracle (OpenMP over chains like MALA.cpp:632) on this box's host cores,
+                  logL only (the reference has no gradient), rank 0 / N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "MALA steps/sec (all chains) + achieved HBM GB/s, 64 chains × 1e5-bin spectrum"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vendor vector fp64 peak (FMA = 2 flop)
+F_ALG_LOGL = 3.7e7             # flop-equivalents per chain-step, logL only (grad ~3x)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chains", type=int, default=64, help="chains per GPU")
+    ap.add_argument("--nx", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import tamcmc_amd
+    from tamcmc_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+        local = 0
+    dev = torch.device("cuda", local)
+
+    # ---- workload (identical on every rank; each rank takes its slice of the temperature ladder)
+    w = synth.workload_c2(model_case=2, Nx=args.nx)
+    nchains = args.chains
+    total_chains = nchains * world
+    P_all = synth.chain_params(w, total_chains)
+    T_all = synth.temperatures(total_chains)
+    sl = slice(rank * nchains, (rank + 1) * nchains)       # contiguous in temperature
+    with tamcmc_amd.Accel(2, w["plength"], w["x"], np.ones(args.nx), device_id=local) as a0:
+        m_true, st = a0.model_explicit(w["params_true"])   # product path builds the synthetic truth
+    assert st == 0
+    y = synth.make_spectrum(m_true)
+
+    acc = tamcmc_amd.Accel(2, w["plength"], w["x"], y, device_id=local)
+    acc.set_vars(w["index_to_relax"])
+    nvars = int(w["index_to_relax"].size)
+    stream = torch.cuda.current_stream(dev)
+    acc.set_stream(stream.cuda_stream)
+    d_params = torch.from_numpy(P_all[sl].copy()).to(dev)
+    d_T = torch.from_numpy(T_all[sl].copy()).to(dev)
+    d_logL = torch.empty(nchains, dtype=torch.float64, device=dev)
+    d_grad = torch.empty(nchains, nvars, dtype=torch.float64, device=dev)
+    d_status = torch.empty(nchains, dtype=torch.int32, device=dev)
+
+    def step(grad=True):
+        acc.eval_batch_device(nchains, d_params.data_ptr(), d_T.data_ptr(), d_logL.data_ptr(),
+                              d_grad.data_ptr() if grad else 0, d_status.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def timed(n, grad):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(grad)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step(True)
+    acc.profile(True)
+    dt = timed(args.steps, True)
+    k_ms, k_n = acc.kernel_time()
+    acc.profile(False)
+    assert int(d_status.abs().sum().item()) == 0, "a chain reported a non-zero status"
+    assert bool(torch.isfinite(d_logL).all()) and bool(torch.isfinite(d_grad).all())
+
+    # secondary: likelihood only (what the reference's sampler actually evaluates per step)
+    for _ in range(max(2, args.warmup // 4)):
+        step(False)
+    acc.profile(True)
+    dt_l = timed(args.steps, False)
+    kl_ms, kl_n = acc.kernel_time()
+    acc.profile(False)
+
+    value = total_chains * args.steps / dt
+    value_l = total_chains * args.steps / dt_l
+    geo = acc.geometry()
+    bytes_per_launch = 16.0 * args.nx * nchains               # B_alg = 16 Nx per chain-step
+    k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
+    kl_avg_s = (kl_ms / max(kl_n, 1)) * 1e-3
+    achieved = bytes_per_launch / k_avg_s / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("eval_grad_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "tamcmc_eval_kernel<grad>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "kernel_ms": round(k_avg_s * 1e3, 4), "launches": int(k_n),
+        "binding_roof": "fp64 VALU (SURVEY.md F6): logL-only kernel at "
+                        f"{nchains / kl_avg_s * F_ALG_LOGL / 1e12 / FP64_VALU_PEAK_TFLOPS:.3f} of {FP64_VALU_PEAK_TFLOPS} TFLOP/s "
+                        "counting SURVEY's 3.7e7 flop-equivalents per chain-step",
+        "logL_only": {"achieved": round(bytes_per_launch / kl_avg_s / 1e9, 2),
+                      "frac": round(bytes_per_launch / kl_avg_s / 1e9 / HBM_PEAK_GBS, 5),
+                      "kernel_ms": round(kl_avg_s * 1e3, 4)},
+    }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as orc       # reported baseline only; never on the product path
+        cores = orc.max_threads()
+        Pc, Tc = P_all[sl], T_all[sl]
+        orc.generate_batch(2, w["plength"], w["x"], y, Pc, Tc)          # warm-up
+        n_it, t0 = 0, time.perf_counter()
+        while True:
+            orc.generate_batch(2, w["plength"], w["x"], y, Pc, Tc)
+            n_it += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds or n_it >= 2000:
+                break
+        cpu = {"value": round(nchains * n_it / el, 2), "unit": "chain-steps/s", "cores": int(cores), "kind": "port",
+               "sample": f"{n_it} iterations x {nchains} chains x {args.nx} bins, logL only (the reference has no "
+                         f"gradient), OpenMP over chains, {el:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": round(value, 1), "unit": "chain-steps/s (model+logL+grad)", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: model_MS_Global_a1etaa3_HarveyLike (id 2), 21 modes l=0..2, 56 params, "
+                                   f"{args.nx} bins, {nchains} chains per GPU, trunc_c=20, logL + gradient over "
+                                   f"{nvars} variables, params resident in HBM",
+                       "chains_total": total_chains, "bins_per_tile_grad": None, "geometry_logL": geo},
+            "logL_only": {"value": round(value_l, 1), "unit": "chain-steps/s (model+logL)",
+                          "ms_per_step": round(dt_l / args.steps * 1e3, 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    acc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

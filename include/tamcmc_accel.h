@@ -1,0 +1,127 @@
+/*
+ * tamcmc_accel.h -- C ABI of the MI355X (gfx950) accelerator for TAMCMC's hot path:
+ * for every parallel-tempered chain at once, params row -> model spectrum M(x) -> tempered
+ * log-likelihood (-> gradient with respect to the relaxed variables).
+ *
+ * This is the drop-in boundary.  It replaces, for the whole batch of chains in one call, what the
+ * reference does per chain inside its OpenMP loop (MALA.cpp:632-639):
+ *
+ *     Model_def::generate_model(Data*, long m, VectorXd Tcoefs)        model_def.cpp:358-367
+ *       -> Model_def::call_model(Data*, int m)                          model_def.cpp:210-289
+ *            -> model_MS_Global_* / model_MS_local_* / model_*_Gaussian models.cpp
+ *       -> Model_def::call_likelihood(Data*, int m, VectorXd Tcoefs)    model_def.cpp:291-320
+ *            -> likelihood_chi22p / likelihood_chi_square               likelihoods.cpp:17-39
+ *
+ * Conventions kept from the reference: all arithmetic fp64; logL is returned ALREADY DIVIDED by the
+ * chain temperature Tcoefs[m] (model_def.cpp:302); the parameter layout is the flat `params` row
+ * described by plength[0..10] (models.cpp:492-506); model / likelihood ids are the
+ * integers of Config/default/models_ctrl.list and likelihoods_ctrl.list.  Where the reference would
+ * print and exit() from inside the path the library reports a per-chain status instead.
+ *
+ * All entry points return TAMCMC_OK (0) or a TAMCMC_E_* code; none of them throws, prints or exits.
+ * There is NO CPU fallback: without a usable HIP device tamcmc_ctx_create fails with
+ * TAMCMC_E_NODEVICE.
+ *
+ * Threading: one ctx = one device + one stream; calls on one ctx must be serialised by the caller;
+ * different ctx objects (other GPUs, other stars) may be driven concurrently from different threads.
+ * Ownership: the library copies x, y, sigma_y to the device at create time and never keeps caller
+ * pointers after a call returns.
+ */
+#ifndef TAMCMC_ACCEL_H
+#define TAMCMC_ACCEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tamcmc_ctx tamcmc_ctx;
+
+/* error codes */
+#define TAMCMC_OK                  0
+#define TAMCMC_E_INVALID           1  /* bad argument (NULL pointer, negative size, plength/Nparams mismatch) */
+#define TAMCMC_E_NODEVICE          2  /* no usable HIP device / device_id out of range                        */
+#define TAMCMC_E_HIP               3  /* a HIP runtime call failed (see tamcmc_last_hip_error)                */
+#define TAMCMC_E_MODEL_DISABLED    4  /* model id 4 or 5: the reference itself exits for these                */
+#define TAMCMC_E_UNKNOWN_MODEL     5  /* id not in models_ctrl.list / likelihoods_ctrl.list                   */
+#define TAMCMC_E_NOMEM             6
+#define TAMCMC_E_NOVARS            7  /* gradient requested before tamcmc_ctx_set_vars                        */
+#define TAMCMC_E_NOGRAD            8  /* gradient not available for this model/likelihood id                  */
+
+/* per-chain status written by the eval calls */
+#define TAMCMC_CHAIN_OK            0
+#define TAMCMC_CHAIN_NAN           1  /* logL is NaN: legal, means "reject" (MALA.cpp:475,507-509)            */
+#define TAMCMC_CHAIN_EMPTY_WINDOW  2  /* a truncation window is empty: the reference would exit(EXIT_FAILURE),
+                                         build_lorentzian.cpp:428-443; logL is set to NaN                      */
+
+/* Replaces: Config::setup() handing `Data` (data.h:24-36) + the integer switches
+ * (config.cpp:95-98) to the Model_def constructor (model_def.cpp:27-55).
+ *   device_id        HIP device ordinal (>= 0).
+ *   model_case       models_ctrl.list id (0..14; 4 and 5 -> TAMCMC_E_MODEL_DISABLED).
+ *   likelihood_case  0 = chi(2,2p), 1 = chi_square.
+ *   likelihood_p     Model_def::likelihood_params; truncated to an integer like the reference's
+ *                    `long p` argument (likelihoods.cpp:17).
+ *   plength          the 11 block lengths of the params row.
+ *   x, y, sigma_y    Nx doubles each on the host; sigma_y may be NULL unless likelihood_case == 1.
+ *                    x must be the regular grid the reference assumes (build_lorentzian.cpp:423). */
+int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case, int likelihood_case,
+                      double likelihood_p, const int32_t plength[11], int64_t Nx,
+                      const double *x, const double *y, const double *sigma_y);
+
+/* Replaces: Model_def::index_to_relax (model_def.cpp:81-88).  Declares which params columns are
+ * the free variables; needed only for gradients.  grad column k = d(logL/T)/d params[index_to_relax[k]]. */
+int tamcmc_ctx_set_vars(tamcmc_ctx *ctx, int32_t Nvars, const int32_t *index_to_relax);
+
+/* Replaces: the `for chain` loop of generate_model() calls (MALA.cpp:632-639, model_def.cpp:139-143).
+ * Host pointers, row-major.  Synchronous: results are valid on return.
+ *   params      Nchains x Nparams
+ *   Tcoefs      Nchains temperatures (MALA.cpp:103)
+ *   logL        Nchains, tempered: logL/T
+ *   grad        NULL, or Nchains x Nvars
+ *   model_rows  n_rows chain indices whose model spectrum is wanted (Model_def::model rows), or NULL
+ *   model_out   n_rows x Nx, or NULL
+ *   status      NULL or Nchains TAMCMC_CHAIN_* codes */
+int tamcmc_eval_batch(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams,
+                      const double *params, const double *Tcoefs,
+                      double *logL, double *grad,
+                      int32_t n_rows, const int32_t *model_rows, double *model_out,
+                      int32_t *status);
+
+/* Same computation with DEVICE pointers (hipMalloc'ed on the ctx device), enqueued on the ctx stream
+ * without synchronising: for a sampler that keeps chain state resident in HBM.
+ * d_grad / d_status may be NULL. */
+int tamcmc_eval_batch_device(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams,
+                             const double *d_params, const double *d_Tcoefs,
+                             double *d_logL, double *d_grad, int32_t *d_status);
+
+/* Replaces: Model_def::call_model_explicit (model_def.cpp:199-208) as used by tools/getmodel.cpp:111.
+ * One params row -> model spectrum (Nx doubles, host).  *status gets the TAMCMC_CHAIN_* code. */
+int tamcmc_model_explicit(tamcmc_ctx *ctx, int32_t Nparams, const double *params,
+                          double *model_out, int32_t *status);
+
+/* Stream plumbing.  hip_stream is a hipStream_t created on the ctx device (NULL = the ctx's own stream). */
+int tamcmc_ctx_set_stream(tamcmc_ctx *ctx, void *hip_stream);
+int tamcmc_ctx_synchronize(tamcmc_ctx *ctx);
+
+/* Kernel timing with HIP events recorded on the ctx stream around the dominant kernel of every
+ * eval call while enabled.  tamcmc_ctx_kernel_time synchronises the stream, then returns the summed
+ * duration and the number of launches since profiling was enabled. */
+int tamcmc_ctx_profile(tamcmc_ctx *ctx, int enable);
+int tamcmc_ctx_kernel_time(tamcmc_ctx *ctx, double *total_ms, int64_t *launches);
+
+/* Launch geometry actually used (for DESIGN.md / bench bookkeeping). */
+int tamcmc_ctx_geometry(tamcmc_ctx *ctx, int32_t *bins_per_tile, int32_t *tiles, int32_t *threads_per_block,
+                        int32_t *n_multiplets);
+
+int tamcmc_ctx_destroy(tamcmc_ctx *ctx);
+
+int tamcmc_device_count(void);
+const char *tamcmc_strerror(int code);
+const char *tamcmc_last_hip_error(void);
+const char *tamcmc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMCMC_ACCEL_H */

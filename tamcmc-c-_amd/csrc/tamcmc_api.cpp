@@ -1,0 +1,463 @@
+// tamcmc_api.cpp -- host side of the C ABI declared in include/tamcmc_accel.h.
+// Owns the device buffers of one context, validates arguments the way Model_def's callers rely on
+// (plength sums to Nparams, model / likelihood ids from the *.list tables), and strings the three
+// launches of one evaluation on the context stream:
+//     setup (params -> multiplet table)  ->  eval (model + likelihood [+ gradient partials])
+//     ->  finalize (fixed-order sum over tiles, -p(..)/T)  [-> backward (chain rule to d/dvars)]
+// No CPU fallback exists in this library.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "tamcmc_accel.h"
+#include "tamcmc_dev.h"
+
+static thread_local char g_hip_err[256] = "";
+
+#define TM_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            snprintf(g_hip_err, sizeof(g_hip_err), "%s -> %s", #call, hipGetErrorString(e_)); \
+            return TAMCMC_E_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+struct tamcmc_ctx {
+    int device = 0;
+    TmLayout L{};
+    int K = 4;                     // bins per thread of the eval kernel, likelihood only
+    int Kg = 2;                    // bins per thread when gradient partials are accumulated (register budget)
+    int tiles = 0;                 // tiles at K
+    int tiles_g = 0;               // tiles at Kg
+    int tiles_max = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // resident data
+    double *d_x = nullptr, *d_y = nullptr, *d_lx = nullptr, *d_isig2 = nullptr;
+    // per-batch buffers (capacity in chains)
+    int cap = 0;
+    bool cap_grad = false;
+    double *d_params = nullptr, *d_T = nullptr, *d_logL = nullptr, *d_part = nullptr;
+    double *d_gmult = nullptr, *d_gnoise = nullptr, *d_grad = nullptr;
+    int32_t *d_status = nullptr, *d_rows = nullptr;
+    TmMult *d_mult = nullptr;
+    TmNoise *d_noise = nullptr;
+    double *d_model = nullptr;
+    size_t model_cap = 0;
+    // variables
+    int Nvars = 0;
+    int32_t *d_relax = nullptr;
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev;   // pairs (start, stop)
+    size_t ev_used = 0;
+};
+
+static int model_supported(int id)
+{
+    if (id == 4 || id == 5) return TAMCMC_E_MODEL_DISABLED;
+    if (id < 0 || id > 14) return TAMCMC_E_UNKNOWN_MODEL;
+    return TAMCMC_OK;
+}
+
+// Build the layout of the params row (models.cpp:492-506, :1696-1710).
+static int build_layout(TmLayout &L, int model_case, int likelihood_case, double like_p, const int32_t plength[11],
+                        int64_t Nx, const double *x)
+{
+    std::memset(&L, 0, sizeof(L));
+    L.model_case = model_case;
+    L.likelihood_case = likelihood_case;
+    L.like_p = (double)(long)like_p;           // `long p`, likelihoods.cpp:17
+    L.Nx = (int32_t)Nx;
+    L.x0 = x[0];
+    L.xlast = x[Nx - 1];
+    L.step = x[1] - x[0];
+    int sum = 0;
+    for (int i = 0; i < 11; i++) { if (plength[i] < 0) return TAMCMC_E_INVALID; sum += plength[i]; }
+    L.Nparams = sum;
+    if (model_case == 0 || model_case == 1) {
+        L.family = TM_FAM_GAUSS;
+        L.n_mult = 0;
+        if (sum < (model_case == 0 ? 4 : 7)) return TAMCMC_E_INVALID;
+        L.nharvey = (model_case == 1) ? 1 : 0;
+        return TAMCMC_OK;
+    }
+    L.family = (model_case == 11 || model_case == 14) ? TM_FAM_LOCAL : TM_FAM_GLOBAL;
+    L.variant = (model_case == 6 || model_case == 7 || model_case == 8) ? 1 : ((model_case == 13 || model_case == 14) ? 2 : 0);
+    L.Nmax = plength[0];
+    L.lmax = plength[1];
+    for (int l = 0; l < 4; l++) L.Nfl[l] = plength[2 + l];
+    L.Nsplit = plength[6]; L.Nwidth = plength[7]; L.Nnoise = plength[8]; L.Ninc = plength[9];
+    const int Nf = L.Nfl[0] + L.Nfl[1] + L.Nfl[2] + L.Nfl[3];
+    L.off_f[0] = L.Nmax + L.lmax;
+    for (int l = 1; l < 4; l++) L.off_f[l] = L.off_f[l - 1] + L.Nfl[l - 1];
+    L.s = L.Nmax + L.lmax + Nf;
+    L.w = L.s + L.Nsplit;
+    L.z = L.w + L.Nwidth;
+    L.q = L.z + L.Nnoise;
+    if (L.q + L.Ninc + 2 > sum) return TAMCMC_E_INVALID;   // trunc_c and do_amp must exist
+    if (L.Nsplit < 6) return TAMCMC_E_INVALID;
+    if (L.Nnoise < 1) return TAMCMC_E_INVALID;
+    if (L.family == TM_FAM_GLOBAL) {
+        if (L.lmax < 0 || L.lmax > 3 || L.Nmax < 1) return TAMCMC_E_INVALID;
+        for (int l = 0; l <= L.lmax; l++) if (L.Nfl[l] != L.Nmax) return TAMCMC_E_INVALID; // models.cpp:485-486
+        L.n_mult = L.Nmax * (L.lmax + 1);
+        L.nharvey = (L.Nnoise - 1) / 3;
+        if (L.nharvey > TM_MAXH) return TAMCMC_E_INVALID;
+        const bool interp = !(model_case == 9 || model_case == 10);
+        if (interp && L.lmax >= 1 && L.Nfl[0] < 2) return TAMCMC_E_INVALID;  // lin_interpol needs two nodes
+        if (interp && L.Nwidth < L.Nmax) return TAMCMC_E_INVALID;
+        if (model_case == 9 && L.Nwidth < 5) return TAMCMC_E_INVALID;
+        if (model_case == 10 && L.Nwidth < 6) return TAMCMC_E_INVALID;
+        if (model_case == 6 && L.Nsplit < 7) return TAMCMC_E_INVALID;
+        if (model_case == 7 && L.Nsplit < 6 + L.Nmax) return TAMCMC_E_INVALID;
+        if (model_case == 8 && L.Nsplit < 6 + 2 * L.Nmax) return TAMCMC_E_INVALID;
+        if (model_case == 12 && L.Ninc < 2 + (L.lmax >= 2 ? 3 : 0) + (L.lmax >= 3 ? 4 : 0)) return TAMCMC_E_INVALID;
+        if (model_case == 13 && L.lmax >= 1 && L.Ninc < (L.lmax + 1) * (L.Nmax - 1) + L.lmax + 1) return TAMCMC_E_INVALID;
+        if ((model_case == 3 || model_case == 6 || model_case == 7 || model_case == 8) && L.Ninc < 1) return TAMCMC_E_INVALID;
+    } else {
+        L.n_mult = Nf;
+        L.nharvey = 0;                         // models.cpp:1818
+        if (Nf < 1) return TAMCMC_E_INVALID;
+        if (L.Nwidth < Nf) return TAMCMC_E_INVALID;
+        if (model_case == 11 && L.Nmax < Nf) return TAMCMC_E_INVALID;
+        if (model_case == 14) {
+            int off = 0;
+            for (int l = 0; l < 4; l++) {
+                if (L.Nfl[l] > 0 && off + (l + 1) * (L.Nfl[l] - 1) + l >= sum) return TAMCMC_E_INVALID;
+                off += L.Nfl[l];
+            }
+        }
+    }
+    return TAMCMC_OK;
+}
+
+static void free_batch(tamcmc_ctx *c)
+{
+    (void)hipFree(c->d_params); (void)hipFree(c->d_T); (void)hipFree(c->d_logL); (void)hipFree(c->d_part);
+    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad);
+    (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
+    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = nullptr;
+    c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
+    c->cap = 0; c->cap_grad = false;
+}
+
+static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
+{
+    if (Nchains <= c->cap && (!grad || c->cap_grad)) return TAMCMC_OK;
+    const int cap = Nchains > c->cap ? Nchains : c->cap;
+    const bool g = grad || c->cap_grad;
+    TM_HIP(hipStreamSynchronize(c->stream));
+    free_batch(c);
+    const size_t n = (size_t)cap;
+    const int nm = c->L.n_mult > 0 ? c->L.n_mult : 1;
+    TM_HIP(hipMalloc(&c->d_params, n * c->L.Nparams * sizeof(double)));
+    TM_HIP(hipMalloc(&c->d_T, n * sizeof(double)));
+    TM_HIP(hipMalloc(&c->d_logL, n * sizeof(double)));
+    TM_HIP(hipMalloc(&c->d_part, n * c->tiles_max * 2 * sizeof(double)));
+    TM_HIP(hipMalloc(&c->d_status, n * sizeof(int32_t)));
+    TM_HIP(hipMalloc(&c->d_rows, n * sizeof(int32_t)));
+    TM_HIP(hipMalloc(&c->d_mult, n * nm * sizeof(TmMult)));
+    TM_HIP(hipMalloc(&c->d_noise, n * sizeof(TmNoise)));
+    if (g) {
+        TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g * nm * TM_GSLOTS * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g * TM_NSLOTS * sizeof(double)));
+        const int nv = c->Nvars > 0 ? c->Nvars : 1;
+        TM_HIP(hipMalloc(&c->d_grad, n * nv * sizeof(double)));
+    }
+    c->cap = cap;
+    c->cap_grad = g;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case, int likelihood_case,
+                                 double likelihood_p, const int32_t plength[11], int64_t Nx,
+                                 const double *x, const double *y, const double *sigma_y)
+{
+    if (!out) return TAMCMC_E_INVALID;
+    *out = nullptr;
+    if (!plength || !x || !y || Nx < 2 || Nx > 0x7fffff00LL) return TAMCMC_E_INVALID;
+    int rc = model_supported(model_case);
+    if (rc != TAMCMC_OK) return rc;
+    if (likelihood_case != 0 && likelihood_case != 1) return TAMCMC_E_UNKNOWN_MODEL;
+    if (likelihood_case == 1 && !sigma_y) return TAMCMC_E_INVALID;
+    const int ndev = tamcmc_device_count();
+    if (ndev <= 0 || device_id < 0 || device_id >= ndev) return TAMCMC_E_NODEVICE;
+
+    tamcmc_ctx *c = new (std::nothrow) tamcmc_ctx();
+    if (!c) return TAMCMC_E_NOMEM;
+    c->device = device_id;
+    rc = build_layout(c->L, model_case, likelihood_case, likelihood_p, plength, Nx, x);
+    if (rc != TAMCMC_OK) { delete c; return rc; }
+
+    const char *ek = getenv("TAMCMC_BINS_PER_THREAD");
+    if (ek) { int k = atoi(ek); if (k == 1 || k == 2 || k == 4 || k == 8) c->K = k; }
+    const char *ekg = getenv("TAMCMC_BINS_PER_THREAD_GRAD");
+    if (ekg) { int k = atoi(ekg); if (k == 1 || k == 2 || k == 4 || k == 8) c->Kg = k; }
+    c->tiles = (int)((Nx + TM_THREADS * c->K - 1) / (TM_THREADS * c->K));
+    c->tiles_g = (int)((Nx + TM_THREADS * c->Kg - 1) / (TM_THREADS * c->Kg));
+    c->tiles_max = c->tiles > c->tiles_g ? c->tiles : c->tiles_g;
+
+    auto fail = [&](int code) { tamcmc_ctx_destroy(c); return code; };
+    if (hipSetDevice(device_id) != hipSuccess) return fail(TAMCMC_E_NODEVICE);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(TAMCMC_E_HIP);
+    c->stream = c->own_stream;
+    const size_t bytes = (size_t)Nx * sizeof(double);
+    if (hipMalloc(&c->d_x, bytes) != hipSuccess || hipMalloc(&c->d_y, bytes) != hipSuccess ||
+        hipMalloc(&c->d_lx, bytes) != hipSuccess)
+        return fail(TAMCMC_E_NOMEM);
+    std::vector<double> tmp((size_t)Nx);
+    for (int64_t i = 0; i < Nx; i++) tmp[(size_t)i] = std::log(x[i]);   // log x table for the Harvey powers
+    if (hipMemcpy(c->d_x, x, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_y, y, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_lx, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(TAMCMC_E_HIP);
+    if (likelihood_case == 1) {
+        for (int64_t i = 0; i < Nx; i++) tmp[(size_t)i] = 1.0 / (sigma_y[i] * sigma_y[i]);  // likelihoods.cpp:36
+        if (hipMalloc(&c->d_isig2, bytes) != hipSuccess) return fail(TAMCMC_E_NOMEM);
+        if (hipMemcpy(c->d_isig2, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(TAMCMC_E_HIP);
+    }
+    *out = c;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
+{
+    if (!c) return TAMCMC_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_batch(c);
+    (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2);
+    (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_set_vars(tamcmc_ctx *c, int32_t Nvars, const int32_t *index_to_relax)
+{
+    if (!c || Nvars < 0 || (Nvars > 0 && !index_to_relax)) return TAMCMC_E_INVALID;
+    for (int i = 0; i < Nvars; i++)
+        if (index_to_relax[i] < 0 || index_to_relax[i] >= c->L.Nparams) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_relax); c->d_relax = nullptr;
+    (void)hipFree(c->d_grad); c->d_grad = nullptr;
+    c->Nvars = Nvars;
+    if (Nvars > 0) {
+        TM_HIP(hipMalloc(&c->d_relax, (size_t)Nvars * sizeof(int32_t)));
+        TM_HIP(hipMemcpy(c->d_relax, index_to_relax, (size_t)Nvars * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (c->cap > 0 && c->cap_grad) TM_HIP(hipMalloc(&c->d_grad, (size_t)c->cap * Nvars * sizeof(double)));
+    }
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_set_stream(tamcmc_ctx *c, void *hip_stream)
+{
+    if (!c) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_synchronize(tamcmc_ctx *c)
+{
+    if (!c) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_profile(tamcmc_ctx *c, int enable)
+{
+    if (!c) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    c->profile = enable != 0;
+    c->ev_used = 0;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_kernel_time(tamcmc_ctx *c, double *total_ms, int64_t *launches)
+{
+    if (!c || !total_ms || !launches) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    double t = 0.0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.f;
+        TM_HIP(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        t += (double)ms;
+    }
+    *total_ms = t;
+    *launches = (int64_t)(c->ev_used / 2);
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_t *tiles, int32_t *threads_per_block,
+                                   int32_t *n_multiplets)
+{
+    if (!c) return TAMCMC_E_INVALID;
+    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K;
+    if (tiles) *tiles = c->tiles;
+    if (threads_per_block) *threads_per_block = TM_THREADS;
+    if (n_multiplets) *n_multiplets = c->L.n_mult;
+    return TAMCMC_OK;
+}
+
+// Enqueue setup -> eval -> finalize (-> backward) for device-resident inputs.
+static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const double *d_T, double *d_logL,
+                   double *d_grad, int32_t *d_status, const int32_t *d_rows, double *d_model)
+{
+    const bool grad = d_grad != nullptr;
+    const int K = grad ? c->Kg : c->K;
+    const int tiles = grad ? c->tiles_g : c->tiles;
+    int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_mult, c->d_noise, c->stream);
+    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    TmEvalArgs a{};
+    a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
+    a.mult = c->d_mult; a.noise = c->d_noise; a.Tcoefs = d_T;
+    a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
+    a.row_of_chain = d_rows; a.model_out = d_model;
+    a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
+    a.like_p = c->L.like_p;
+    if (c->profile) {
+        while (c->ev.size() < c->ev_used + 2) {
+            hipEvent_t e;
+            TM_HIP(hipEventCreate(&e));
+            c->ev.push_back(e);
+        }
+        TM_HIP(hipEventRecord(c->ev[c->ev_used], c->stream));
+    }
+    rc = tm_launch_eval(a, Nchains, K, grad, c->stream);
+    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "eval launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    if (c->profile) {
+        TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    rc = tm_launch_finalize(c->L, Nchains, tiles, c->d_part, c->d_noise, d_T, d_logL, d_status, c->stream);
+    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "finalize launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    if (grad) {
+        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K, d_params, d_T, c->d_mult, c->d_gmult,
+                                c->d_gnoise, c->Nvars, c->d_relax, d_grad, c->stream);
+        if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    }
+    return TAMCMC_OK;
+}
+
+static int grad_supported(const tamcmc_ctx *c)
+{
+    if (c->Nvars <= 0 || !c->d_relax) return TAMCMC_E_NOVARS;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_eval_batch_device(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams,
+                                        const double *d_params, const double *d_Tcoefs,
+                                        double *d_logL, double *d_grad, int32_t *d_status)
+{
+    if (!c || Nchains < 1 || !d_params || !d_Tcoefs || !d_logL) return TAMCMC_E_INVALID;
+    if (Nparams != c->L.Nparams) return TAMCMC_E_INVALID;
+    if (d_grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }
+    TM_HIP(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, Nchains, d_grad != nullptr);
+    if (rc != TAMCMC_OK) return rc;
+    return enqueue(c, Nchains, d_params, d_Tcoefs, d_logL, d_grad, d_status, nullptr, nullptr);
+}
+
+extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams,
+                                 const double *params, const double *Tcoefs,
+                                 double *logL, double *grad,
+                                 int32_t n_rows, const int32_t *model_rows, double *model_out,
+                                 int32_t *status)
+{
+    if (!c || Nchains < 1 || !params || !Tcoefs || !logL) return TAMCMC_E_INVALID;
+    if (Nparams != c->L.Nparams) return TAMCMC_E_INVALID;
+    if (n_rows < 0 || (n_rows > 0 && (!model_rows || !model_out))) return TAMCMC_E_INVALID;
+    for (int r = 0; r < n_rows; r++)
+        if (model_rows[r] < 0 || model_rows[r] >= Nchains) return TAMCMC_E_INVALID;
+    if (grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }
+    TM_HIP(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, Nchains, grad != nullptr);
+    if (rc != TAMCMC_OK) return rc;
+
+    const size_t n = (size_t)Nchains;
+    TM_HIP(hipMemcpyAsync(c->d_params, params, n * Nparams * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    TM_HIP(hipMemcpyAsync(c->d_T, Tcoefs, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int32_t *d_rows = nullptr;
+    if (n_rows > 0) {
+        std::vector<int32_t> rows(n, -1);
+        for (int r = 0; r < n_rows; r++) rows[(size_t)model_rows[r]] = r;   // a chain listed twice keeps the last row
+        const size_t need = (size_t)n_rows * (size_t)c->L.Nx;
+        if (need > c->model_cap) {
+            TM_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_model); c->d_model = nullptr; c->model_cap = 0;
+            TM_HIP(hipMalloc(&c->d_model, need * sizeof(double)));
+            c->model_cap = need;
+        }
+        TM_HIP(hipMemcpyAsync(c->d_rows, rows.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        TM_HIP(hipStreamSynchronize(c->stream));   // rows is a local
+        d_rows = c->d_rows;
+    }
+    rc = enqueue(c, Nchains, c->d_params, c->d_T, c->d_logL, grad ? c->d_grad : nullptr, c->d_status, d_rows, c->d_model);
+    if (rc != TAMCMC_OK) return rc;
+    TM_HIP(hipMemcpyAsync(logL, c->d_logL, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) TM_HIP(hipMemcpyAsync(status, c->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (grad) TM_HIP(hipMemcpyAsync(grad, c->d_grad, n * c->Nvars * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (n_rows > 0) {
+        // rows whose chain was listed more than once share one device row
+        for (int r = 0; r < n_rows; r++) {
+            int src = r;
+            for (int r2 = n_rows - 1; r2 > r; r2--) if (model_rows[r2] == model_rows[r]) { src = r2; break; }
+            TM_HIP(hipMemcpyAsync(model_out + (size_t)r * c->L.Nx, c->d_model + (size_t)src * c->L.Nx,
+                                  (size_t)c->L.Nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    TM_HIP(hipStreamSynchronize(c->stream));
+    TM_HIP(hipGetLastError());
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_model_explicit(tamcmc_ctx *c, int32_t Nparams, const double *params, double *model_out, int32_t *status)
+{
+    if (!c || !params || !model_out) return TAMCMC_E_INVALID;
+    const double T = 1.0;
+    double logL = 0.0;
+    const int32_t row = 0;
+    int32_t st = 0;
+    int rc = tamcmc_eval_batch(c, 1, Nparams, params, &T, &logL, nullptr, 1, &row, model_out, &st);
+    if (status) *status = st;
+    return rc;
+}
+
+extern "C" const char *tamcmc_strerror(int code)
+{
+    switch (code) {
+    case TAMCMC_OK: return "ok";
+    case TAMCMC_E_INVALID: return "invalid argument";
+    case TAMCMC_E_NODEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case TAMCMC_E_HIP: return "HIP runtime error (see tamcmc_last_hip_error)";
+    case TAMCMC_E_MODEL_DISABLED: return "model id disabled in the reference (ids 4, 5)";
+    case TAMCMC_E_UNKNOWN_MODEL: return "unknown model or likelihood id";
+    case TAMCMC_E_NOMEM: return "out of memory";
+    case TAMCMC_E_NOVARS: return "gradient requested before tamcmc_ctx_set_vars";
+    case TAMCMC_E_NOGRAD: return "gradient not available for this model";
+    default: return "unknown error code";
+    }
+}
+
+extern "C" const char *tamcmc_last_hip_error(void) { return g_hip_err; }
+extern "C" const char *tamcmc_version(void) { return "tamcmc_accel 0.1 (gfx950)"; }

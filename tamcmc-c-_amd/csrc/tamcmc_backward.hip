@@ -1,0 +1,314 @@
+// tamcmc_backward.hip -- chain rule from the eval kernel's per-multiplet partial sums to
+// d(logL/T)/d vars.  NOT in the reference (its sampler never had a gradient: MALA.cpp:18,317-333;
+// SURVEY.md F2 / App. D): this is new functionality, validated against finite differences of the
+// CPU oracle's log-likelihood only ("parity unpinned").  The truncation window [imin,imax) moves
+// with the parameters; like any analytic gradient of a truncated model this ignores the motion.
+//
+// One workgroup (one wave) per chain.  Phase 1: lane j re-derives multiplet j (tamcmc_derive.h),
+// sums its partials over the tiles its window touches IN TILE ORDER, and emits (param index, value)
+// pairs plus chain-level adjoints into LDS.  Phase 2: lane 0 turns the chain-level adjoints
+// (splitting, inclination, visibilities, asymmetry, numax, noise) into more pairs.  Phase 3: lane k
+// gathers, in pair order, everything addressed to variable k.  No atomics: bitwise reproducible.
+// Compiled with -ffp-contract=off because it shares tamcmc_derive.h with the setup kernel.
+#include <hip/hip_runtime.h>
+#include "tamcmc_dev.h"
+#include "tamcmc_derive.h"
+
+#define TM_NPAIR 12   // pairs a multiplet can emit
+#define TM_NSHARED 20 // chain-level adjoint slots per multiplet
+#define TM_NCPAIR 64  // base number of chain-level pairs (plus numax pairs for id 9)
+
+// chain-level slots
+#define SL_A1 0
+#define SL_FS1 1
+#define SL_FS2 2
+#define SL_ETA 3
+#define SL_A3 4
+#define SL_ASYM 5
+#define SL_V 6      // +l-1, l=1..3
+#define SL_RATIO 9  // l=1: 9,10  l=2: 11,12,13  l=3: 14..17
+#define SL_NUMAX 18
+
+__device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + (l == 1 ? 0 : l == 2 ? 2 : 5) + am; }
+__device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
+
+__global__ __launch_bounds__(64) void tamcmc_backward_kernel(TmLayout L, int tiles, int TB,
+                                                             const double *__restrict__ params,
+                                                             const double *__restrict__ Tcoefs,
+                                                             const TmMult *__restrict__ mult,
+                                                             const double *__restrict__ gmult,
+                                                             const double *__restrict__ gnoise,
+                                                             int Nvars, const int32_t *__restrict__ relax,
+                                                             double *__restrict__ grad)
+{
+    const double PI = 3.141592653589793238462643383279502884;
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    const double *p = params + (size_t)chain * L.Nparams;
+    extern __shared__ double s_dyn[];
+    __shared__ TmChain C;
+    const int nm = L.n_mult;
+    // dynamic LDS carve-up
+    double *pair_val = s_dyn;                                  // [nm*TM_NPAIR + ncp]
+    const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
+    const int npairs_max = nm * TM_NPAIR + ncp;
+    double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
+    int *pair_idx = reinterpret_cast<int *>(shared_adj + (size_t)nm * TM_NSHARED);  // [npairs_max]
+
+    for (int e = tid; e < npairs_max; e += 64) { pair_idx[e] = -1; pair_val[e] = 0.0; }
+    for (int e = tid; e < nm * TM_NSHARED; e += 64) shared_adj[e] = 0.0;
+    if (tid == 0 && L.family != TM_FAM_GAUSS) tm_derive_chain(L, p, C);
+    __syncthreads();
+
+    // ---------------- phase 1: per multiplet ----------------
+    for (int j = tid; j < nm; j += 64) {
+        TmMultFull M;
+        tm_derive_mult(L, C, p, j, M);
+        double *sh = shared_adj + (size_t)j * TM_NSHARED;
+        int *pi = pair_idx + j * TM_NPAIR;
+        double *pv = pair_val + j * TM_NPAIR;
+        int np = 0;
+        if (M.status != 0) continue;
+        double G[TM_GSLOTS];
+        for (int s = 0; s < TM_GSLOTS; s++) G[s] = 0.0;
+        const int t0 = M.imin / TB, t1 = (M.imax - 1) / TB;
+        for (int t = t0; t <= t1 && t < tiles; t++) {
+            const double *g = gmult + (((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS;
+            for (int s = 0; s < 3 * M.ncomp; s++) G[s] += g[s];
+            for (int s = 21; s < 24; s++) G[s] += g[s];
+        }
+        const int l = M.l;
+        const double W = M.W, g2 = W * W, f = M.f;
+        double adj_g2 = 0.0, adj_f = 0.0, adj_W = 0.0, adj_fs = 0.0;
+        double adj_h[TM_MAXM];
+        for (int k = 0; k < M.ncomp; k++) {
+            const double hq = M.h[k] * g2;
+            const double adj_hq = G[3 * k];
+            const double adj_nu = 4.0 * hq * G[3 * k + 1];
+            adj_g2 += -hq * G[3 * k + 2] + adj_hq * M.h[k];
+            adj_h[k] = adj_hq * g2;
+            const int m = k - l;
+            if (l != 0) {
+                adj_f += adj_nu * (1. + C.eta * M.Q[k]);
+                sh[SL_ETA] += adj_nu * f * M.Q[k];
+                adj_fs += adj_nu * (double)m;
+                sh[SL_A3] += adj_nu * M.c[k];
+            } else {
+                adj_f += adj_nu;
+            }
+        }
+        adj_W += 2.0 * W * adj_g2;
+        if (C.asym != 0) {
+            const double al = C.asym;
+            const double cc = 0.5 * W * al / f, c2 = cc * cc;
+            const double C0 = G[21], C1 = G[22], C2 = G[23];
+            sh[SL_ASYM] += 2.0 * (C2 / f - C1) + (2.0 * c2 / al) * C0;
+            adj_W += (2.0 * c2 / W) * C0;
+            adj_f += -2.0 * al / (f * f) * C2 - (2.0 * c2 / f) * C0;
+        }
+        // splitting
+        if (L.variant == 1) {
+            double a1s = 0.0, a2s = 0.0;
+            if (l == 1) a1s = adj_fs;
+            if (l == 2) a2s = adj_fs;
+            if (l == 3) { a1s = 0.5 * adj_fs; a2s = 0.5 * adj_fs; }
+            if (L.model_case == 6) { sh[SL_FS1] += a1s; sh[SL_FS2] += a2s; }
+            if (L.model_case == 7) { pi[np] = L.s + 6 + M.n; pv[np] = tm_sign(p[L.s + 6 + M.n]) * (a1s + a2s); np++; }
+            if (L.model_case == 8) {
+                pi[np] = L.s + 6 + M.n; pv[np] = tm_sign(p[L.s + 6 + M.n]) * a1s; np++;
+                pi[np] = L.s + 6 + L.Nmax + M.n; pv[np] = tm_sign(p[L.s + 6 + L.Nmax + M.n]) * a2s; np++;
+            }
+        } else {
+            sh[SL_A1] += adj_fs;
+        }
+        // heights
+        const double piW = PI * W;
+        if (L.variant != 2) {
+            double adj_H = 0.0;
+            for (int k = 0; k < M.ncomp; k++) {
+                adj_H += adj_h[k] * C.ratios[l][k];
+                if (l > 0) { int am = k - l; if (am < 0) am = -am; sh[tm_ratio_slot(l, am)] += adj_h[k] * M.H; }
+            }
+            const double pn = p[M.idx_h];
+            const bool plain = (l == 0 || L.family == TM_FAM_LOCAL);
+            const double Vl = plain ? 1.0 : C.Vl[l];
+            const double scale = C.do_amp ? 1.0 / piW : 1.0;
+            pi[np] = M.idx_h; pv[np] = tm_sign(pn) * scale * Vl * adj_H; np++;
+            if (!plain) sh[SL_V + l - 1] += fabs(pn) * scale * adj_H;
+            if (C.do_amp) adj_W += -M.H / W * adj_H;
+        } else {
+            if (l == 0) {
+                const double scale = C.do_amp ? 1.0 / piW : 1.0;
+                pi[np] = M.idx_h; pv[np] = tm_sign(p[M.idx_h]) * scale * adj_h[0]; np++;
+                if (C.do_amp) adj_W += -M.h[0] / W * adj_h[0];
+            } else {
+                const double scale = C.do_amp ? 1.0 / piW : 1.0;
+                for (int am = 0; am <= l; am++) {
+                    double a = adj_h[l + am];
+                    if (am > 0) a += adj_h[l - am];
+                    pi[np] = M.idx_h + am; pv[np] = tm_sign(p[M.idx_h + am]) * scale * a; np++;
+                    if (C.do_amp) adj_W += -M.h[l + am] / W * a;
+                }
+            }
+        }
+        // width
+        if (M.width_kind == 0) {
+            pi[np] = M.idx_w0; pv[np] = tm_sign(M.Wraw) * adj_W; np++;
+        } else if (M.width_kind == 1) {
+            const double adj_v = tm_sign(M.Wraw) * adj_W;
+            const double F0 = p[M.idx_F0], F1 = p[M.idx_F1];
+            const double t = (f - F0) / (F1 - F0), a = M.slope;
+            adj_f += a * adj_v;
+            pi[np] = M.idx_w0; pv[np] = (1.0 - t) * adj_v; np++;
+            pi[np] = M.idx_w1; pv[np] = t * adj_v; np++;
+            pi[np] = M.idx_F0; pv[np] = a * (t - 1.0) * adj_v; np++;
+            pi[np] = M.idx_F1; pv[np] = -a * t * adj_v; np++;
+        } else {
+            const int w = L.w;
+            const double adj_ln = W * adj_W;
+            if (M.width_kind == 2) {
+                const double numax = C.numax;
+                const double N = log(f / p[w + 0]), D = log(p[w + 3] / numax), A = log(p[w + 4]);
+                const double e = 2. * N / D, q1 = 1. + e * e;
+                const double dLde = 2.0 * A * e / (q1 * q1);
+                pi[np] = w + 1; pv[np] = adj_ln * log(f / numax); np++;
+                pi[np] = w + 2; pv[np] = adj_ln / p[w + 2]; np++;
+                pi[np] = w + 4; pv[np] = -adj_ln / (p[w + 4] * q1); np++;
+                pi[np] = w + 0; pv[np] = adj_ln * dLde * (-2.0 / (p[w + 0] * D)); np++;
+                pi[np] = w + 3; pv[np] = adj_ln * dLde * (-2.0 * N / (D * D * p[w + 3])); np++;
+                adj_f += adj_ln * (p[w + 1] / f + dLde * 2.0 / (f * D));
+                sh[SL_NUMAX] += adj_ln * (-p[w + 1] / numax + dLde * 2.0 * N / (D * D * numax));
+            } else {
+                const double N = log(f / p[w + 1]), D = log(p[w + 4] / p[w + 0]), A = log(p[w + 5]);
+                const double e = 2. * N / D, q1 = 1. + e * e;
+                const double dLde = 2.0 * A * e / (q1 * q1);
+                pi[np] = w + 2; pv[np] = adj_ln * log(f / p[w + 0]); np++;
+                pi[np] = w + 3; pv[np] = adj_ln / p[w + 3]; np++;
+                pi[np] = w + 5; pv[np] = -adj_ln / (p[w + 5] * q1); np++;
+                pi[np] = w + 1; pv[np] = adj_ln * dLde * (-2.0 / (p[w + 1] * D)); np++;
+                pi[np] = w + 4; pv[np] = adj_ln * dLde * (-2.0 * N / (D * D * p[w + 4])); np++;
+                pi[np] = w + 0; pv[np] = adj_ln * (-p[w + 2] / p[w + 0] + dLde * 2.0 * N / (D * D * p[w + 0])); np++;
+                adj_f += adj_ln * (p[w + 2] / f + dLde * 2.0 / (f * D));
+            }
+        }
+        pi[np] = M.idx_f; pv[np] = adj_f; np++;
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: chain-level adjoints and noise (lane 0) ----------------
+    if (tid == 0) {
+        int *pi = pair_idx + nm * TM_NPAIR;
+        double *pv = pair_val + nm * TM_NPAIR;
+        int np = 0;
+        if (L.family != TM_FAM_GAUSS) {
+            double S[TM_NSHARED];
+            for (int s = 0; s < TM_NSHARED; s++) S[s] = 0.0;
+            for (int j = 0; j < nm; j++)
+                for (int s = 0; s < TM_NSHARED; s++) S[s] += shared_adj[(size_t)j * TM_NSHARED + s];
+            const int id = L.model_case, s0 = L.s, q = L.q;
+            pi[np] = s0 + 1; pv[np] = S[SL_ETA]; np++;
+            pi[np] = s0 + 2; pv[np] = S[SL_A3]; np++;
+            pi[np] = s0 + 5; pv[np] = S[SL_ASYM]; np++;
+            if (id == 6) {
+                pi[np] = s0; pv[np] = tm_sign(p[s0]) * S[SL_FS1]; np++;
+                pi[np] = s0 + 6; pv[np] = tm_sign(p[s0 + 6]) * S[SL_FS2]; np++;
+            }
+            // inclination adjoint from the ratio adjoints
+            double adj_inc = 0.0;
+            for (int l = 1; l <= 3; l++)
+                for (int am = 0; am <= l; am++) adj_inc += S[tm_ratio_slot(l, am)] * C.dratios[l][l + am];
+            if (id == 12) {
+                const int base[4] = {0, 0, 2, 5};
+                for (int l = 1; l <= L.lmax; l++)
+                    for (int am = 0; am <= l; am++) {
+                        pi[np] = q + base[l] + am; pv[np] = tm_sign(p[q + base[l] + am]) * S[tm_ratio_slot(l, am)]; np++;
+                    }
+            }
+            if (id == 2 || id == 9 || id == 10 || id == 11) {
+                const double pa = p[s0 + 3], pb = p[s0 + 4], r2 = pa * pa + pb * pb;
+                pi[np] = s0 + 3; pv[np] = 2.0 * pa * S[SL_A1] + adj_inc * (180. / PI) * (-pb / r2); np++;
+                pi[np] = s0 + 4; pv[np] = 2.0 * pb * S[SL_A1] + adj_inc * (180. / PI) * (pa / r2); np++;
+            } else {
+                if (id == 3 || id == 12 || id == 13 || id == 14) { pi[np] = s0; pv[np] = tm_sign(p[s0]) * S[SL_A1]; np++; }
+                if (id == 3 || id == 6 || id == 7 || id == 8) { pi[np] = q; pv[np] = adj_inc; np++; }
+            }
+            double adj_V[4] = {0.0, S[SL_V], S[SL_V + 1], S[SL_V + 2]};
+            if (id == 9) {
+                // numax = sum_n p_n (F0_n + sum_l V_l F_l,n) / sum_n p_n (1 + sum_l V_l), models.cpp:1372-1390
+                const double an = S[SL_NUMAX], numax = C.numax, Htot = C.Htot;
+                double vsum = 1.0;
+                for (int l = 1; l <= L.lmax; l++) vsum += C.Vl[l];
+                for (int n = 0; n < L.Nmax; n++) {
+                    double fsum = p[L.off_f[0] + n];
+                    for (int l = 1; l <= L.lmax; l++) fsum += C.Vl[l] * p[L.off_f[l] + n];
+                    pi[np] = n; pv[np] = an * (fsum - numax * vsum) / Htot; np++;
+                    pi[np] = L.off_f[0] + n; pv[np] = an * p[n] / Htot; np++;
+                    for (int l = 1; l <= L.lmax; l++) {
+                        pi[np] = L.off_f[l] + n; pv[np] = an * p[n] * C.Vl[l] / Htot; np++;
+                        adj_V[l] += an * p[n] * (p[L.off_f[l] + n] - numax) / Htot;
+                    }
+                }
+            }
+            if (L.family == TM_FAM_GLOBAL && id != 13)
+                for (int l = 1; l <= L.lmax; l++) { pi[np] = L.Nmax + l - 1; pv[np] = tm_sign(p[L.Nmax + l - 1]) * adj_V[l]; np++; }
+        }
+        // noise terms: sum the per-tile partials in tile order
+        double Gn[TM_NSLOTS];
+        for (int s = 0; s < TM_NSLOTS; s++) Gn[s] = 0.0;
+        for (int t = 0; t < tiles; t++) {
+            const double *g = gnoise + ((size_t)chain * tiles + t) * TM_NSLOTS;
+            for (int s = 0; s < TM_NSLOTS; s++) Gn[s] += g[s];
+        }
+        int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
+        bool take_abs = true;
+        if (L.model_case == 0) { z = 3; Nnoise = 1; nharvey = 0; take_abs = false; }
+        if (L.model_case == 1) { z = 3; Nnoise = 4; nharvey = 1; }
+        const double sw = Gn[3 * TM_MAXH];
+        int slot = 0;
+        for (int k = 0; k < nharvey; k++) {
+            const double Hs = p[z + 3 * k], ts = p[z + 3 * k + 1], ps = p[z + 3 * k + 2];
+            const double H = fabs(Hs), tau = fabs(ts), pw = fabs(ps);
+            if (tau != 0) {
+                if (pw == 0) { pi[np] = z + 3 * k; pv[np] = tm_sign(Hs) * 0.5 * sw; np++; continue; }
+                const double B1 = Gn[3 * slot], B2 = Gn[3 * slot + 1], B3 = Gn[3 * slot + 2];
+                pi[np] = z + 3 * k;     pv[np] = tm_sign(Hs) * B1; np++;
+                pi[np] = z + 3 * k + 1; pv[np] = tm_sign(ts) * (-H * pw / tau * B2); np++;
+                pi[np] = z + 3 * k + 2; pv[np] = tm_sign(ps) * (-H * B3); np++;
+                slot++;
+            }
+        }
+        pi[np] = z + Nnoise - 1; pv[np] = (take_abs ? tm_sign(p[z + Nnoise - 1]) : 1.0) * sw; np++;
+        if (L.family == TM_FAM_GAUSS) {
+            const double E0 = Gn[13], E1 = Gn[14], E2 = Gn[15];
+            const double gA = (L.model_case == 0) ? p[0] : fabs(p[0]);
+            const double s2 = p[1] * p[1];
+            pi[np] = 0; pv[np] = ((L.model_case == 0) ? 1.0 : tm_sign(p[0])) * E0; np++;
+            pi[np] = 2; pv[np] = gA * E1 / s2; np++;
+            pi[np] = 1; pv[np] = 0.5 * gA * E2 / (s2 * s2) * 2.0 * p[1]; np++;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: gather per variable, in pair order ----------------
+    for (int k = tid; k < Nvars; k += 64) {
+        const int target = relax[k];
+        double acc = 0.0;
+        for (int e = 0; e < npairs_max; e++)
+            if (pair_idx[e] == target) acc += pair_val[e];
+        grad[(size_t)chain * Nvars + k] = acc;
+    }
+}
+
+int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
+                       const double *d_Tcoefs, const TmMult *d_mult, const double *d_gmult, const double *d_gnoise,
+                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, void *stream)
+{
+    const int nm = L.n_mult;
+    const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
+    const int npairs_max = nm * TM_NPAIR + ncp;
+    const size_t lds = (size_t)npairs_max * sizeof(double) + (size_t)nm * TM_NSHARED * sizeof(double) +
+                       (size_t)npairs_max * sizeof(int);
+    if (lds > 60 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(64), lds, (hipStream_t)stream, L, tiles,
+                       bins_per_tile, d_params, d_Tcoefs, d_mult, d_gmult, d_gnoise, Nvars, d_index_to_relax, d_grad);
+    return (int)hipGetLastError();
+}

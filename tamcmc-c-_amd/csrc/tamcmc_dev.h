@@ -1,0 +1,95 @@
+// tamcmc_dev.h -- structures shared by the host side of the C ABI and the gfx950 kernels.
+//
+// Data layout in HBM (all fp64 unless noted), one set per ctx (= one star on one GPU):
+//   x[Nx], y[Nx], lx[Nx]=log(x), isig2[Nx]=1/sigma_y^2 (chi_square only)      resident, written at create
+//   params[Nchains][Nparams], Tcoefs[Nchains]                                 per call (or caller-resident)
+//   mult[Nchains][n_mult]   : TmMult  -- per-chain multiplet table written by the setup kernel
+//   noise[Nchains]          : TmNoise -- Harvey / white-noise / Gaussian terms per chain
+//   part[Nchains][tiles][2] : per-tile partial sums of the likelihood (fixed-order reduction)
+//   gmult[Nchains][tiles][n_mult][TM_GSLOTS], gnoise[Nchains][tiles][TM_NSLOTS] : gradient partials
+//   logL[Nchains], status[Nchains] (int32), grad[Nchains][Nvars]
+#pragma once
+#include <stdint.h>
+
+#define TM_MAXM 7      // components of a multiplet: 2l+1, l <= 3 (build_lorentzian.cpp:74)
+#define TM_MAXH 4      // Harvey profiles per chain (Nnoise = 3*Nharvey+1, models.cpp:624)
+#define TM_THREADS 256 // threads per workgroup of the eval kernel (4 waves of 64)
+#define TM_CHUNK 16    // multiplets staged in LDS per pass
+#define TM_GSLOTS 24   // gradient partials per (tile, multiplet): 3 per component + 3 asymmetry sums
+#define TM_NSLOTS 16   // gradient partials per tile for the noise terms: 3 per Harvey + N0 (+pad)
+
+// model families (how the params row is unpacked)
+#define TM_FAM_GAUSS  0  // ids 0, 1          models.cpp:1968-2034
+#define TM_FAM_GLOBAL 1  // ids 2,3,6-10,12,13 models.cpp:15-1674
+#define TM_FAM_LOCAL  2  // ids 11, 14        models.cpp:1683-1963
+
+struct TmLayout {
+    int32_t model_case;   // models_ctrl.list id
+    int32_t family;
+    int32_t variant;      // 0 a1etaa3, 1 a1l_etaa3, 2 a1etaa3_v2 (heights per m)   build_lorentzian.cpp
+    int32_t Nmax, lmax;   // plength[0], plength[1] (local models: Nvis)
+    int32_t Nfl[4];       // plength[2..5]
+    int32_t Nsplit, Nwidth, Nnoise, Ninc;
+    int32_t off_f[4];     // first index of the degree-l frequencies
+    int32_t s, w, z, q;   // splitting, widths, noise, inclination blocks
+    int32_t Nparams;      // sum(plength)
+    int32_t n_mult;       // multiplets per chain
+    int32_t nharvey;      // Harvey profiles evaluated (0 for local models, models.cpp:1818)
+    int32_t likelihood_case;
+    int32_t Nx;
+    int32_t pad;
+    double  x0, xlast, step;  // x[0], x[Nx-1], x[1]-x[0] (models.cpp:489)
+    double  like_p;           // (double)(long)likelihood_params
+};
+
+struct TmMult {
+    double g2;            // Gamma^2
+    double aA, aB, c2;    // asymmetry: a = x*aA + aB, A(x) = a*a + c2   (build_lorentzian.cpp:96)
+    double nu2[TM_MAXM];  // 2*nu_lm
+    double hq[TM_MAXM];   // h_lm * Gamma^2
+    int32_t imin, imax;   // truncation window [imin, imax)  (build_lorentzian.cpp:423-427)
+    int32_t ncomp;        // 2l+1
+    int32_t has_asym;
+};
+static_assert(sizeof(TmMult) == 160, "TmMult layout");
+#define TM_MULT_DOUBLES 20
+
+struct TmNoise {
+    double H[TM_MAXH];    // |H_k|                 (harvey1985: |H_k|*|tau_k|)
+    double lt[TM_MAXH];   // log(1e-3*|tau_k|)     (harvey1985: log(1e-3*2pi*|tau_k|))
+    double p[TM_MAXH];    // |p_k|
+    double N0;            // white noise (last noise parameter)
+    double gA, gnu0, gs2; // Gaussian term amp*exp(-0.5 (x-nu0)^2 / s2) of ids 0, 1
+    int32_t nh;           // active Harvey profiles (tau != 0)
+    int32_t has_gauss;
+    int32_t status;       // TAMCMC_CHAIN_* from the setup kernel
+    int32_t pad;
+};
+
+struct TmEvalArgs {
+    const double *x, *y, *lx, *isig2;
+    const TmMult *mult;
+    const TmNoise *noise;
+    const double *Tcoefs;
+    double *part;               // [Nchains][tiles][2]
+    double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL
+    double *gnoise;             // [Nchains][tiles][TM_NSLOTS] or NULL
+    const int32_t *row_of_chain;// NULL or [Nchains]: row of model_out to fill, -1 none
+    double *model_out;
+    int32_t Nx, n_mult, tiles, likelihood_case;
+    double like_p;
+};
+
+#ifdef __cplusplus
+extern "C++" {
+// launchers implemented in the .hip files
+struct ihipStream_t;
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise, void *stream);
+int tm_launch_eval(const TmEvalArgs &a, int Nchains, int K, bool grad, void *stream);
+int tm_launch_finalize(const TmLayout &L, int Nchains, int tiles, const double *d_part, const TmNoise *d_noise,
+                       const double *d_Tcoefs, double *d_logL, int32_t *d_status, void *stream);
+int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
+                       const double *d_Tcoefs, const TmMult *d_mult, const double *d_gmult, const double *d_gnoise,
+                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, void *stream);
+}
+#endif

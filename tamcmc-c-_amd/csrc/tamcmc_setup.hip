@@ -1,0 +1,86 @@
+// tamcmc_setup.hip -- per-chain prologue kernel: params row -> multiplet table + noise terms.
+// Compiled with -ffp-contract=off (see tamcmc_derive.h).
+//
+// One workgroup (one wave of 64) per chain.  Lane 0 derives the chain-level quantities into LDS,
+// then lanes stride over the chain's multiplets.  The work is O(Nparams) per chain (microseconds);
+// it exists as a kernel so that a sampler can keep params resident in HBM and chain the whole
+// evaluation on one stream (or in one hipGraph) without a host round trip.
+#include <hip/hip_runtime.h>
+#include "tamcmc_dev.h"
+#include "tamcmc_derive.h"
+
+__global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
+                                                          TmMult *__restrict__ mult, TmNoise *__restrict__ noise)
+{
+    const int chain = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double *p = params + (size_t)chain * L.Nparams;
+    __shared__ TmChain C;
+    __shared__ int s_status;
+
+    if (tid == 0) {
+        s_status = 0;
+        if (L.family != TM_FAM_GAUSS) tm_derive_chain(L, p, C);
+    }
+    __syncthreads();
+
+    if (L.family != TM_FAM_GAUSS) {
+        for (int j = tid; j < L.n_mult; j += 64) {
+            TmMultFull M;
+            tm_derive_mult(L, C, p, j, M);
+            TmMult out;
+            const double g2 = M.W * M.W;
+            out.g2 = g2;
+            if (C.asym == 0) {
+                out.aA = 0.0; out.aB = 1.0; out.c2 = 0.0; out.has_asym = 0;
+            } else {
+                // A(x) = (1 + asym (x/f - 1))^2 + (0.5 Gamma asym / f)^2, build_lorentzian.cpp:96
+                const double cc = 0.5 * M.W * C.asym / M.f;
+                out.aA = C.asym / M.f; out.aB = 1.0 - C.asym; out.c2 = cc * cc; out.has_asym = 1;
+            }
+            for (int k = 0; k < TM_MAXM; k++) {
+                if (k < M.ncomp) { out.nu2[k] = 2.0 * M.nu[k]; out.hq[k] = M.h[k] * g2; }
+                else             { out.nu2[k] = 0.0;           out.hq[k] = 0.0; }
+            }
+            out.imin = M.imin; out.imax = M.imax; out.ncomp = M.ncomp;
+            if (M.status != 0) atomicMax(&s_status, M.status);
+            mult[(size_t)chain * L.n_mult + j] = out;
+        }
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        TmNoise N;
+        for (int k = 0; k < TM_MAXH; k++) { N.H[k] = 0.0; N.lt[k] = 0.0; N.p[k] = 0.0; }
+        N.N0 = 0.0; N.gA = 0.0; N.gnu0 = 0.0; N.gs2 = 1.0; N.nh = 0; N.has_gauss = 0; N.pad = 0;
+        int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
+        bool take_abs = true;
+        if (L.model_case == 0) {
+            // model_Test_Gaussian, models.cpp:2021-2034 (no abs anywhere)
+            N.has_gauss = 1; N.gA = p[0]; N.gnu0 = p[2]; N.gs2 = p[1] * p[1];
+            z = 3; Nnoise = 1; nharvey = 0; take_abs = false;
+        } else if (L.model_case == 1) {
+            // model_Harvey_Gaussian, models.cpp:1968-1992
+            N.has_gauss = 1; N.gA = fabs(p[0]); N.gnu0 = p[2]; N.gs2 = fabs(p[1]) * fabs(p[1]);
+            z = 3; Nnoise = 4; nharvey = 1;
+        }
+        double extra = 0.0;
+        for (int k = 0; k < nharvey; k++) {
+            const double H = fabs(p[z + 3 * k]), tau = fabs(p[z + 3 * k + 1]), pw = fabs(p[z + 3 * k + 2]);
+            if (tau != 0) {                           // noise_models.cpp:31
+                if (pw == 0) { extra = extra + H * 0.5; continue; } // (..)^0 = 1 for every bin
+                N.H[N.nh] = H; N.lt[N.nh] = log((1e-3) * tau); N.p[N.nh] = pw; N.nh++;
+            }
+        }
+        const double n0 = p[z + Nnoise - 1];
+        N.N0 = (take_abs ? fabs(n0) : n0) + extra;
+        N.status = s_status;
+        noise[chain] = N;
+    }
+}
+
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise, void *stream)
+{
+    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(64), 0, (hipStream_t)stream, L, d_params, d_mult, d_noise);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,12 @@
+"""Loader: exposes the package directory ``tamcmc-c-_amd/`` (not a valid identifier) as ``tamcmc_amd``."""
+import importlib.util
+import os
+import sys
+
+_pkg_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tamcmc-c-_amd")
+_spec = importlib.util.spec_from_file_location(
+    "tamcmc_amd", os.path.join(_pkg_dir, "__init__.py"), submodule_search_locations=[_pkg_dir]
+)
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["tamcmc_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,220 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Tolerances (written here once):
+    log-likelihood  : |dL| <= 1e-10 * |L|          (north-star: "log-L within 1e-10 relative")
+    model spectrum  : max |dM|/M <= 1e-12 per bin
+    status codes    : identical
+    gradient        : vs Richardson finite differences of the ORACLE logL, 2e-5 relative to the
+                      largest gradient entry of the chain (FD noise floor; the reference has no gradient)
+"""
+import numpy as np
+import pytest
+
+import workloads as W
+from tamcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LOGL = 1e-10
+RTOL_MODEL = 1e-12
+
+
+def spectrum_for(orc, w, seed=17):
+    m, st = orc.model(w["model_case"], w["params_true"], w["plength"], w["x"])
+    assert st == 0
+    return synth.make_spectrum(m, seed=seed)
+
+
+def check_logL(a, b):
+    assert np.all(np.isfinite(b))
+    assert np.max(np.abs(a - b) / np.abs(b)) <= RTOL_LOGL, (a, b)
+
+
+@pytest.mark.parametrize("mid", W.ALL_IDS)
+@pytest.mark.parametrize("kw", [dict(), dict(asym=25.0), dict(do_amp=True, trunc_c=10000.0), dict(asym=-40.0, do_amp=True, trunc_c=7.0)],
+                         ids=["plain", "asym", "amp-notrunc", "asym-amp-c7"])
+def test_model_and_logL_every_id(accel_mod, orc, mid, kw):
+    w = W.any_model(mid, Nx=5000, **kw)       # 5000 bins: not a multiple of any tile size
+    y = spectrum_for(orc, w)
+    n = 6
+    P = W.perturbed(w, n, scale=0.004)
+    T = synth.temperatures(n)
+    with accel_mod.Accel(mid, w["plength"], w["x"], y) as acc:
+        logL, st, models = acc.eval_batch(P, T, model_rows=list(range(n)))
+    rL, rst, rmodels = orc.generate_batch(mid, w["plength"], w["x"], y, P, T, want_models=True)
+    assert np.array_equal(st, rst) and np.all(st == 0)
+    assert np.max(np.abs(models - rmodels) / rmodels) <= RTOL_MODEL
+    check_logL(logL, rL)
+
+
+@pytest.mark.parametrize("mid", [0, 1, 2, 11])
+def test_chi_square_likelihood(accel_mod, orc, mid):
+    w = W.any_model(mid, Nx=3000)
+    y = spectrum_for(orc, w)
+    sig = 0.05 + 0.2 * np.abs(np.sin(np.arange(y.size)))
+    P = W.perturbed(w, 4, scale=0.003)
+    T = synth.temperatures(4)
+    with accel_mod.Accel(mid, w["plength"], w["x"], y, sigma_y=sig, likelihood_case=1) as acc:
+        logL, st = acc.eval_batch(P, T)
+    rL, rst = orc.generate_batch(mid, w["plength"], w["x"], y, P, T, sigma_y=sig, likelihood_case=1)
+    assert np.array_equal(st, rst)
+    check_logL(logL, rL)
+
+
+def test_likelihood_p_is_truncated_like_the_reference(accel_mod, orc):
+    w = W.make(2, Nx=2000)
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 2)
+    T = np.ones(2)
+    with accel_mod.Accel(2, w["plength"], w["x"], y, likelihood_p=2.9) as acc:
+        logL, _ = acc.eval_batch(P, T)
+    rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, P, T, likelihood_p=2.9)
+    check_logL(logL, rL)
+    with accel_mod.Accel(2, w["plength"], w["x"], y, likelihood_p=1.0) as acc:
+        logL1, _ = acc.eval_batch(P, T)
+    assert np.allclose(logL, 2.0 * logL1, rtol=1e-14)
+
+
+@pytest.mark.parametrize("Nx", [2, 3, 255, 256, 257, 1023, 1024, 1025, 4099])
+def test_ragged_sizes(accel_mod, orc, Nx):
+    w = W.make_gauss(1, Nx=Nx)
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 3, scale=0.01)
+    T = synth.temperatures(3)
+    with accel_mod.Accel(1, w["plength"], w["x"], y) as acc:
+        logL, st, models = acc.eval_batch(P, T, model_rows=[2, 0])
+    rL, rst, rm = orc.generate_batch(1, w["plength"], w["x"], y, P, T, want_models=True)
+    check_logL(logL, rL)
+    assert np.max(np.abs(models[0] - rm[2]) / rm[2]) <= RTOL_MODEL
+    assert np.max(np.abs(models[1] - rm[0]) / rm[0]) <= RTOL_MODEL
+
+
+@pytest.mark.parametrize("Nx", [300, 1500, 4097])
+def test_ragged_sizes_lorentzian(accel_mod, orc, Nx):
+    w = W.make(2, Nx=Nx)
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 3, scale=0.003)
+    T = synth.temperatures(3)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        logL, st = acc.eval_batch(P, T)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst)
+    check_logL(logL, rL)
+
+
+def test_status_codes_nan_and_empty_window(accel_mod, orc):
+    w = W.make(2, Nx=3000)
+    b = W.split(w)
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 4, scale=0.002)
+    P[1, b["q"] + 1] = -1.0            # negative trunc_c -> empty window (reference: exit)
+    P[2, b["z"] + 9] = np.nan          # NaN white noise -> NaN logL -> "reject"
+    T = synth.temperatures(4)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        logL, st = acc.eval_batch(P, T)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert list(st) == [0, 2, 1, 0] == list(rst)
+    assert np.isnan(logL[1]) and np.isnan(logL[2])
+    check_logL(logL[[0, 3]], rL[[0, 3]])
+
+
+def test_modes_outside_the_grid_and_window_clamps(accel_mod, orc):
+    w = W.make(2, Nx=6000)
+    b = W.split(w)
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 3, scale=0.001)
+    f0 = b["Nmax"] + b["lmax"]
+    P[0, f0] = 2000.0                   # l=0 mode far below the grid (pmax reset to x0 + c)
+    P[1, f0 + 3 * b["Nmax"] - 1] = 5000.0   # l=2 mode far above the grid (pmin reset to x_last - c)
+    P[2, b["w"]:b["w"] + b["Nmax"]] = 0.3   # widths < 1 -> the Gamma <= 1 window branches
+    T = np.ones(3)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        logL, st, models = acc.eval_batch(P, T, model_rows=[0, 1, 2])
+    rL, rst, rm = orc.generate_batch(2, w["plength"], w["x"], y, P, T, want_models=True)
+    assert np.array_equal(st, rst)
+    assert np.max(np.abs(models - rm) / rm) <= RTOL_MODEL
+    check_logL(logL, rL)
+
+
+def test_full_size_c2_64_chains(accel_mod, orc):
+    """BASELINE config C2: 64 chains x 1e5 bins, model id 2 (and id 3), against the oracle."""
+    for mid in (2, 3):
+        w = synth.workload_c2(model_case=mid)
+        y = spectrum_for(orc, w)
+        P = synth.chain_params(w, 64)
+        T = synth.temperatures(64)
+        with accel_mod.Accel(mid, w["plength"], w["x"], y) as acc:
+            logL, st = acc.eval_batch(P, T)
+            logL2, _ = acc.eval_batch(P, T)
+        rL, rst = orc.generate_batch(mid, w["plength"], w["x"], y, P, T)
+        assert np.array_equal(st, rst) and np.all(st == 0)
+        check_logL(logL, rL)
+        assert np.array_equal(logL, logL2)          # fixed-order reductions: bitwise reproducible
+
+
+def test_full_size_c4_106_params(accel_mod, orc):
+    w = synth.workload_c4()
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 16)
+    T = synth.temperatures(16)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        logL, st = acc.eval_batch(P, T)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst)
+    check_logL(logL, rL)
+
+
+def test_c1_local_basic(accel_mod, orc):
+    w = synth.workload_c1()
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 8)
+    T = synth.temperatures(8)
+    with accel_mod.Accel(11, w["plength"], w["x"], y) as acc:
+        logL, st = acc.eval_batch(P, T)
+    rL, rst = orc.generate_batch(11, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst)
+    check_logL(logL, rL)
+
+
+def test_size_independent_properties_full_size(accel_mod, orc):
+    """Properties that need no oracle: tempering is a pure 1/T scale, chains are independent of their
+    position in the batch, and the mode part of the model is linear in the heights."""
+    w = synth.workload_c2()
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 32)
+    T = synth.temperatures(32)
+    b = W.split(w)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        L, _ = acc.eval_batch(P, T)
+        L1, _ = acc.eval_batch(P, np.ones(32))
+        perm = np.random.default_rng(1).permutation(32)
+        Lp, _ = acc.eval_batch(P[perm], T[perm])
+        p0 = w["params_true"].copy(); p0[:b["Nmax"]] = 0.0
+        p3 = w["params_true"].copy(); p3[:b["Nmax"]] *= 3.0
+        m, _ = acc.model_explicit(w["params_true"])
+        mb, _ = acc.model_explicit(p0)
+        m3, _ = acc.model_explicit(p3)
+    assert np.allclose(L, L1 / T, rtol=1e-15)
+    assert np.array_equal(Lp, L[perm])
+    assert np.allclose(m3 - mb, 3.0 * (m - mb), rtol=1e-11, atol=1e-13)
+
+
+def test_model_def_mirror(accel_mod, orc):
+    """The Model_def-shaped host mirror: generate_model(m) per chain == generate_models() batched."""
+    from tamcmc_amd.model_def import ModelDef, Data
+    w = W.make(2, Nx=3000)
+    y = spectrum_for(orc, w)
+    T = synth.temperatures(4)
+    md = ModelDef(Data(w["x"], y), 2, w["plength"], w["params_true"], w["relax"], T, prior_fct=lambda p: -0.5)
+    md.vars[:] = W.perturbed(w, 4, scale=0.003)[:, md.index_to_relax]
+    for m in range(4):
+        md.update_params_with_vars(m)
+    post = md.generate_models(model_rows=[0]).copy()
+    single = np.array([md.generate_model(md.data, m, T) for m in range(4)])
+    assert np.array_equal(post, single)
+    rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, md.params, T)
+    check_logL(md.logLikelihood, rL)
+    assert np.allclose(md.logPosterior, md.logLikelihood - 0.5)
+    rm, _ = orc.model(2, md.params[0], w["plength"], w["x"])
+    assert np.max(np.abs(md.model[0] - rm) / rm) <= RTOL_MODEL
+    assert np.max(np.abs(md.call_model(md.data, 0) - rm) / rm) <= RTOL_MODEL
+    md.close()
