@@ -30,8 +30,8 @@ static thread_local char g_hip_err[256] = "";
 struct tamcmc_ctx {
     int device = 0;
     TmLayout L{};
-    int K = 4;                     // bins per thread of the eval kernel, likelihood only
-    int Kg = 2;                    // bins per thread when gradient partials are accumulated (register budget)
+    int K = 4, S = 2;              // likelihood only: KU bins in flight per thread, S sub-blocks -> 2048-bin tiles
+    int Kg = 2, Sg = 8;            // with gradient partials: smaller KU (register budget), 4096-bin tiles
     int tiles = 0;                 // tiles at K
     int tiles_g = 0;               // tiles at Kg
     int tiles_max = 0;
@@ -107,6 +107,7 @@ static int build_layout(TmLayout &L, int model_case, int likelihood_case, double
         if (L.lmax < 0 || L.lmax > 3 || L.Nmax < 1) return TAMCMC_E_INVALID;
         for (int l = 0; l <= L.lmax; l++) if (L.Nfl[l] != L.Nmax) return TAMCMC_E_INVALID; // models.cpp:485-486
         L.n_mult = L.Nmax * (L.lmax + 1);
+        if (L.n_mult > TM_MAXMULT) return TAMCMC_E_INVALID;
         L.nharvey = (L.Nnoise - 1) / 3;
         if (L.nharvey > TM_MAXH) return TAMCMC_E_INVALID;
         const bool interp = !(model_case == 9 || model_case == 10);
@@ -122,6 +123,7 @@ static int build_layout(TmLayout &L, int model_case, int likelihood_case, double
         if ((model_case == 3 || model_case == 6 || model_case == 7 || model_case == 8) && L.Ninc < 1) return TAMCMC_E_INVALID;
     } else {
         L.n_mult = Nf;
+        if (L.n_mult > TM_MAXMULT) return TAMCMC_E_INVALID;
         L.nharvey = 0;                         // models.cpp:1818
         if (Nf < 1) return TAMCMC_E_INVALID;
         if (L.Nwidth < Nf) return TAMCMC_E_INVALID;
@@ -202,12 +204,21 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     rc = build_layout(c->L, model_case, likelihood_case, likelihood_p, plength, Nx, x);
     if (rc != TAMCMC_OK) { delete c; return rc; }
 
-    const char *ek = getenv("TAMCMC_BINS_PER_THREAD");
-    if (ek) { int k = atoi(ek); if (k == 1 || k == 2 || k == 4 || k == 8) c->K = k; }
-    const char *ekg = getenv("TAMCMC_BINS_PER_THREAD_GRAD");
-    if (ekg) { int k = atoi(ekg); if (k == 1 || k == 2 || k == 4 || k == 8) c->Kg = k; }
-    c->tiles = (int)((Nx + TM_THREADS * c->K - 1) / (TM_THREADS * c->K));
-    c->tiles_g = (int)((Nx + TM_THREADS * c->Kg - 1) / (TM_THREADS * c->Kg));
+    auto env_int = [](const char *name, int lo, int hi, int *dst) {
+        const char *e = getenv(name);
+        if (e) { int v = atoi(e); if (v >= lo && v <= hi) *dst = v; }
+    };
+    env_int("TAMCMC_KU", 1, 4, &c->K);
+    env_int("TAMCMC_S", 1, 64, &c->S);
+    env_int("TAMCMC_KU_GRAD", 1, 4, &c->Kg);
+    env_int("TAMCMC_S_GRAD", 1, 16, &c->Sg);
+    if (c->K == 3) c->K = 4;
+    if (c->Kg == 3) c->Kg = 2;
+    {
+        const int64_t TB = (int64_t)TM_THREADS * c->K * c->S, TBg = (int64_t)TM_THREADS * c->Kg * c->Sg;
+        c->tiles = (int)((Nx + TB - 1) / TB);
+        c->tiles_g = (int)((Nx + TBg - 1) / TBg);
+    }
     c->tiles_max = c->tiles > c->tiles_g ? c->tiles : c->tiles_g;
 
     auto fail = [&](int code) { tamcmc_ctx_destroy(c); return code; };
@@ -312,7 +323,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
                                    int32_t *n_multiplets)
 {
     if (!c) return TAMCMC_E_INVALID;
-    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K;
+    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K * c->S;
     if (tiles) *tiles = c->tiles;
     if (threads_per_block) *threads_per_block = TM_THREADS;
     if (n_multiplets) *n_multiplets = c->L.n_mult;
@@ -325,6 +336,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
 {
     const bool grad = d_grad != nullptr;
     const int K = grad ? c->Kg : c->K;
+    const int S = grad ? c->Sg : c->S;
     const int tiles = grad ? c->tiles_g : c->tiles;
     int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_mult, c->d_noise, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
@@ -335,6 +347,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.row_of_chain = d_rows; a.model_out = d_model;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
+    a.S = S;
     if (c->profile) {
         while (c->ev.size() < c->ev_used + 2) {
             hipEvent_t e;
@@ -352,7 +365,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     rc = tm_launch_finalize(c->L, Nchains, tiles, c->d_part, c->d_noise, d_T, d_logL, d_status, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "finalize launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     if (grad) {
-        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K, d_params, d_T, c->d_mult, c->d_gmult,
+        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, d_T, c->d_mult, c->d_gmult,
                                 c->d_gnoise, c->Nvars, c->d_relax, d_grad, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }

@@ -32,7 +32,8 @@
 __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + (l == 1 ? 0 : l == 2 ? 2 : 5) + am; }
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
-__global__ __launch_bounds__(64) void tamcmc_backward_kernel(TmLayout L, int tiles, int TB,
+#define TM_BW_THREADS 256
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int TB,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmMult *__restrict__ mult,
@@ -43,24 +44,34 @@ __global__ __launch_bounds__(64) void tamcmc_backward_kernel(TmLayout L, int til
 {
     const double PI = 3.141592653589793238462643383279502884;
     const int chain = blockIdx.x, tid = threadIdx.x;
-    const double *p = params + (size_t)chain * L.Nparams;
     extern __shared__ double s_dyn[];
     __shared__ TmChain C;
+    __shared__ double s_gn[TM_NSLOTS];
     const int nm = L.n_mult;
-    // dynamic LDS carve-up
-    double *pair_val = s_dyn;                                  // [nm*TM_NPAIR + ncp]
+    // dynamic LDS carve-up: the chain's params row first (every later access is an LDS read)
+    double *p = s_dyn;                                         // [Nparams]
+    for (int e = tid; e < L.Nparams; e += TM_BW_THREADS) p[e] = params[(size_t)chain * L.Nparams + e];
+    double *pair_val = s_dyn + L.Nparams;                      // [nm*TM_NPAIR + ncp]
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
     int *pair_idx = reinterpret_cast<int *>(shared_adj + (size_t)nm * TM_NSHARED);  // [npairs_max]
 
-    for (int e = tid; e < npairs_max; e += 64) { pair_idx[e] = -1; pair_val[e] = 0.0; }
-    for (int e = tid; e < nm * TM_NSHARED; e += 64) shared_adj[e] = 0.0;
+    for (int e = tid; e < npairs_max; e += TM_BW_THREADS) { pair_idx[e] = -1; pair_val[e] = 0.0; }
+    for (int e = tid; e < nm * TM_NSHARED; e += TM_BW_THREADS) shared_adj[e] = 0.0;
+    __syncthreads();
     if (tid == 0 && L.family != TM_FAM_GAUSS) tm_derive_chain(L, p, C);
+    // noise partials: one lane per slot, tiles in order (independent loads, pipelined)
+    if (tid >= 64 && tid < 64 + TM_NSLOTS) {
+        const int sl = tid - 64;
+        double acc = 0.0;
+        for (int t = 0; t < tiles; t++) acc += gnoise[((size_t)chain * tiles + t) * TM_NSLOTS + sl];
+        s_gn[sl] = acc;
+    }
     __syncthreads();
 
     // ---------------- phase 1: per multiplet ----------------
-    for (int j = tid; j < nm; j += 64) {
+    for (int j = tid; j < nm; j += TM_BW_THREADS) {
         TmMultFull M;
         tm_derive_mult(L, C, p, j, M);
         double *sh = shared_adj + (size_t)j * TM_NSHARED;
@@ -252,12 +263,7 @@ __global__ __launch_bounds__(64) void tamcmc_backward_kernel(TmLayout L, int til
                 for (int l = 1; l <= L.lmax; l++) { pi[np] = L.Nmax + l - 1; pv[np] = tm_sign(p[L.Nmax + l - 1]) * adj_V[l]; np++; }
         }
         // noise terms: sum the per-tile partials in tile order
-        double Gn[TM_NSLOTS];
-        for (int s = 0; s < TM_NSLOTS; s++) Gn[s] = 0.0;
-        for (int t = 0; t < tiles; t++) {
-            const double *g = gnoise + ((size_t)chain * tiles + t) * TM_NSLOTS;
-            for (int s = 0; s < TM_NSLOTS; s++) Gn[s] += g[s];
-        }
+        const double *Gn = s_gn;
         int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
         bool take_abs = true;
         if (L.model_case == 0) { z = 3; Nnoise = 1; nharvey = 0; take_abs = false; }
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(64) void tamcmc_backward_kernel(TmLayout L, int til
     __syncthreads();
 
     // ---------------- phase 3: gather per variable, in pair order ----------------
-    for (int k = tid; k < Nvars; k += 64) {
+    for (int k = tid; k < Nvars; k += TM_BW_THREADS) {
         const int target = relax[k];
         double acc = 0.0;
         for (int e = 0; e < npairs_max; e++)
@@ -305,10 +311,15 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_t
     const int nm = L.n_mult;
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
-    const size_t lds = (size_t)npairs_max * sizeof(double) + (size_t)nm * TM_NSHARED * sizeof(double) +
-                       (size_t)npairs_max * sizeof(int);
-    if (lds > 60 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(64), lds, (hipStream_t)stream, L, tiles,
+    const size_t lds = (size_t)L.Nparams * sizeof(double) + (size_t)npairs_max * sizeof(double) +
+                       (size_t)nm * TM_NSHARED * sizeof(double) + (size_t)npairs_max * sizeof(int);
+    if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tamcmc_backward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
                        bins_per_tile, d_params, d_Tcoefs, d_mult, d_gmult, d_gnoise, Nvars, d_index_to_relax, d_grad);
     return (int)hipGetLastError();
 }

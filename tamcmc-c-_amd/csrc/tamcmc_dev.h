@@ -14,7 +14,7 @@
 #define TM_MAXM 7      // components of a multiplet: 2l+1, l <= 3 (build_lorentzian.cpp:74)
 #define TM_MAXH 4      // Harvey profiles per chain (Nnoise = 3*Nharvey+1, models.cpp:624)
 #define TM_THREADS 256 // threads per workgroup of the eval kernel (4 waves of 64)
-#define TM_CHUNK 16    // multiplets staged in LDS per pass
+#define TM_MAXMULT 256 // multiplets per chain (Nmax*(lmax+1) or sum Nfl); staged in LDS, 160 B each
 #define TM_GSLOTS 24   // gradient partials per (tile, multiplet): 3 per component + 3 asymmetry sums
 #define TM_NSLOTS 16   // gradient partials per tile for the noise terms: 3 per Harvey + N0 (+pad)
 
@@ -77,6 +77,7 @@ struct TmEvalArgs {
     const int32_t *row_of_chain;// NULL or [Nchains]: row of model_out to fill, -1 none
     double *model_out;
     int32_t Nx, n_mult, tiles, likelihood_case;
+    int32_t S, pad;             // sub-blocks of 256*KU bins per tile
     double like_p;
 };
 
@@ -85,7 +86,7 @@ extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise, void *stream);
-int tm_launch_eval(const TmEvalArgs &a, int Nchains, int K, bool grad, void *stream);
+int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
 int tm_launch_finalize(const TmLayout &L, int Nchains, int tiles, const double *d_part, const TmNoise *d_noise,
                        const double *d_Tcoefs, double *d_logL, int32_t *d_status, void *stream);
 int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,

@@ -10,20 +10,28 @@
 //   likelihood_chi22p / _chi_square  likelihoods.cpp:17-39
 //
 // Mapping to gfx950 (wave64):
-//   grid = (tiles, chains); workgroup = 256 threads = 4 waves; a tile is 256*K consecutive bins and
-//   thread t owns bins base + k*256 + t (k < K), so every global load is a coalesced 8-byte-per-lane
-//   stream (x, y, log x: 24 B per bin; the 2.4 MB working set of a 1e5-bin star lives in L2).
+//   grid = (tiles, chains); workgroup = 256 threads = 4 waves.  A tile is S sub-blocks of 256*KU
+//   consecutive bins; thread t owns bins base + (u*KU + k)*256 + t, so every global load is a
+//   coalesced 8-byte-per-lane stream (x, y, log x: 24 B per bin; the 2.4 MB working set of a 1e5-bin
+//   star stays in L2).  KU bins are processed together (instruction-level parallelism across the
+//   reciprocal's latency); the sub-block loop is NOT unrolled, so the register footprint is set by
+//   KU while the work per reduction is set by KU*S.
 //   The chain's multiplets whose window meets the tile are compacted (ballot, in table order, so the
-//   summation order is fixed) and staged in LDS in chunks of TM_CHUNK; every thread then walks the
-//   staged list with wave-uniform control flow.
+//   summation order is fixed) and staged once per tile in LDS; every thread walks the staged list
+//   with wave-uniform control flow and broadcast LDS reads.
 //   Arithmetic per Lorentzian component: d = 2x - 2nu; E = d*d + Gamma^2 (2 fp64 ops); one
 //   reciprocal per MULTIPLET via batch inversion (prefix products of the E's), not per component:
 //   sum_m h_m Gamma^2 / E_m.  This is algebraically the reference's H V_m / (1 + 4 (x-nu_m)^2/Gamma^2)
 //   and differs from it only in rounding (<~1e-15 relative per bin).
+//   Harvey profiles: (1e-3 tau x)^p = exp(p (log(1e-3 tau) + log x)) with a log x table; inside a
+//   tile exp(p log x) = t_center * exp(z), |z| <= 0.04, by an 8th-degree Taylor polynomial (error
+//   < 1e-18); wider tiles in log x fall back to a full exp per bin.
 //   Sum of log M: mantissas are multiplied and exponents added per bin (v_frexp_*), one log per
 //   thread and tile instead of one per bin.
-//   Reductions: wave shuffles -> one LDS slot per wave -> one partial per (chain, tile); the final
-//   sum over tiles runs in a fixed order in tamcmc_finalize_kernel (no atomics: bitwise reproducible).
+//   Reductions: likelihood: wave shuffles -> one LDS slot per wave -> one partial per (chain, tile);
+//   gradient: a transposing butterfly (V values per lane cost ~V exchanges, not 6V) -> LDS -> one
+//   partial per (chain, tile, multiplet, slot).  The sums over tiles run in a fixed order in
+//   tamcmc_finalize_kernel / tamcmc_backward_kernel (no atomics anywhere: bitwise reproducible).
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
 
@@ -48,7 +56,61 @@ __device__ __forceinline__ double tm_wave_sum(double v)
     return v;
 }
 
-// Sum over the m-components of one multiplet at one bin, optionally returning every 1/E_m.
+// exp(z) for |z| <= 0.04: Taylor degree 8, truncation error < 0.04^9/9! = 7e-19
+__device__ __forceinline__ double tm_exp_small(double z)
+{
+    double p = 1.0 / 40320.0;
+    p = __builtin_fma(p, z, 1.0 / 5040.0);
+    p = __builtin_fma(p, z, 1.0 / 720.0);
+    p = __builtin_fma(p, z, 1.0 / 120.0);
+    p = __builtin_fma(p, z, 1.0 / 24.0);
+    p = __builtin_fma(p, z, 1.0 / 6.0);
+    p = __builtin_fma(p, z, 0.5);
+    p = __builtin_fma(p, z, 1.0);
+    p = __builtin_fma(p, z, 1.0);
+    return p;
+}
+
+// ---- transposing butterfly: sums N values per lane over the 64 lanes of a wave -------------------
+// One step with lane mask MASK halves the number of live values: lanes with the bit set keep the upper
+// half.  After all steps lane L holds the total of slot tm_bfly_slot<N>(L) (replicated over the lane
+// bits that were reduced plainly).  Cost: ~N exchanges instead of 6N.
+template <int N, int MASK>
+struct TmBfly {
+    static constexpr int NE = (N + 1) & ~1;   // padded to even
+    static constexpr int H = NE / 2;
+    __device__ static __forceinline__ void run(double (&v)[TM_GSLOTS], int lane)
+    {
+        if constexpr (N == 1) {
+            v[0] += __shfl_xor(v[0], MASK, 64);
+        } else {
+            const bool hi = (lane & MASK) != 0;
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                const double up = (i + H < N) ? v[i + H] : 0.0;
+                const double send = hi ? v[i] : up;
+                const double keep = hi ? up : v[i];
+                v[i] = keep + __shfl_xor(send, MASK, 64);
+            }
+        }
+        if constexpr (MASK > 1) TmBfly<(N == 1 ? 1 : H), MASK / 2>::run(v, lane);
+    }
+    // index (at this level) of the value lane `lane` ends up holding; valid = false if it is padding
+    __device__ static __forceinline__ int slot_of(int lane, bool &valid)
+    {
+        if constexpr (N == 1) {
+            return 0;
+        } else {
+            int sub = 0;
+            if constexpr (MASK > 1) sub = TmBfly<H, MASK / 2>::slot_of(lane, valid);
+            const int idx = sub + (((lane & MASK) != 0) ? H : 0);
+            if (idx >= N) valid = false;
+            return idx;
+        }
+    }
+};
+
+// Sum over the m-components of one multiplet at one bin, also returning d_m and every 1/E_m.
 template <int NC>
 __device__ __forceinline__ double tm_mult_value(double x2, const double (&nu2)[NC], const double (&hq)[NC], double g2,
                                                 double (&d)[NC], double (&r)[NC])
@@ -75,9 +137,9 @@ __device__ __forceinline__ double tm_mult_value(double x2, const double (&nu2)[N
     return s;
 }
 
-// Forward: add multiplet `sm` (LDS) to acc[] for this thread's K bins.
-template <int NC, int K>
-__device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x2)[K], const int (&bi)[K], double (&acc)[K])
+// Forward: add multiplet `sm` (LDS) to acc[] for KU bins.
+template <int NC, int KU>
+__device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x2)[KU], const int (&bi)[KU], double (&acc)[KU])
 {
     double nu2[NC], hq[NC];
 #pragma unroll
@@ -87,7 +149,7 @@ __device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x
     const bool has_asym = sm->has_asym != 0;
     const double aAh = 0.5 * sm->aA, aB = sm->aB, c2 = sm->c2;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < KU; k++) {
         double d[NC], r[NC];
         double s = tm_mult_value<NC>(x2[k], nu2, hq, g2, d, r);
         if (has_asym) {
@@ -99,13 +161,15 @@ __device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x
     }
 }
 
-// Backward: per-component partial sums of this thread for multiplet `sm`.
+// Backward: accumulate this thread's partial sums for multiplet `sm` over all S sub-blocks, reduce over
+// the wave and leave the wave totals in s_red_row[slot].
 //   g[3m+0] = sum wA r_m, g[3m+1] = sum wA d_m r_m^2, g[3m+2] = sum wA r_m^2   (d = 2x - 2nu, r = 1/E)
-//   g[21..23] = sum w S, sum w S a, sum w S a x    (S = un-asymmetrised multiplet sum; only if asym != 0)
-template <int NC, int K>
-__device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double (&x2)[K], const int (&bi)[K],
-                                             const double (&w)[K], double *s_red_row, int lane)
+//   g[3NC..3NC+2] = sum w S, sum w S a, sum w S a x   (S = un-asymmetrised multiplet sum; zero if asym == 0)
+template <int NC, int KU>
+__device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__restrict__ gx, const double *s_w,
+                                             int base, int S, int Nx, int tid, int lane, double *s_red_row)
 {
+    constexpr int V = 3 * NC + 3;
     double g[TM_GSLOTS];
     double nu2[NC], hq[NC];
 #pragma unroll
@@ -116,185 +180,241 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double (&x2
     const double aAh = 0.5 * sm->aA, aB = sm->aB, c2 = sm->c2;
 #pragma unroll
     for (int s = 0; s < TM_GSLOTS; s++) g[s] = 0.0;
+#pragma unroll 1
+    for (int u = 0; u < S; u++) {
+        // skip sub-blocks that do not meet the window (wave-uniform: bounds of the whole sub-block)
+        const int lo = base + u * KU * TM_THREADS, hi = lo + KU * TM_THREADS;
+        if (hi <= imin || lo >= imax) continue;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        double d[NC], r[NC];
-        const double S = tm_mult_value<NC>(x2[k], nu2, hq, g2, d, r);
-        const bool inside = (bi[k] >= imin) && (bi[k] < imax);
-        const double wk = inside ? w[k] : 0.0;
-        double wA = wk;
-        if (has_asym) {
-            const double a = __builtin_fma(x2[k], aAh, aB);
-            wA = wk * __builtin_fma(a, a, c2);
-            const double ws = wk * S;
-            g[21] += ws;
-            g[22] = __builtin_fma(ws, a, g[22]);
-            g[23] = __builtin_fma(ws * a, 0.5 * x2[k], g[23]);
-        }
+        for (int k = 0; k < KU; k++) {
+            const int i = lo + k * TM_THREADS + tid;
+            const bool inside = (i >= imin) && (i < imax) && (i < Nx);
+            const double x2 = 2.0 * gx[i < Nx ? i : Nx - 1];
+            const double wk = inside ? s_w[(u * KU + k) * TM_THREADS + tid] : 0.0;
+            double d[NC], r[NC];
+            const double Sv = tm_mult_value<NC>(x2, nu2, hq, g2, d, r);
+            double wA = wk;
+            if (has_asym) {
+                const double a = __builtin_fma(x2, aAh, aB);
+                wA = wk * __builtin_fma(a, a, c2);
+                const double ws = wk * Sv;
+                g[3 * NC + 0] += ws;
+                g[3 * NC + 1] = __builtin_fma(ws, a, g[3 * NC + 1]);
+                g[3 * NC + 2] = __builtin_fma(ws * a, 0.5 * x2, g[3 * NC + 2]);
+            }
 #pragma unroll
-        for (int m = 0; m < NC; m++) {
-            const double t1 = wA * r[m];
-            const double t2 = t1 * r[m];
-            g[3 * m + 0] += t1;
-            g[3 * m + 1] = __builtin_fma(t2, d[m], g[3 * m + 1]);
-            g[3 * m + 2] += t2;
+            for (int m = 0; m < NC; m++) {
+                const double t1 = wA * r[m];
+                const double t2 = t1 * r[m];
+                g[3 * m + 0] += t1;
+                g[3 * m + 1] = __builtin_fma(t2, d[m], g[3 * m + 1]);
+                g[3 * m + 2] += t2;
+            }
         }
     }
-    // wave-level reduction with compile-time slot indices (a runtime-indexed g[] would live in scratch)
-#pragma unroll
-    for (int s = 0; s < 3 * NC; s++) {
-        const double v = tm_wave_sum(g[s]);
-        if (lane == 0) s_red_row[s] = v;
-    }
-#pragma unroll
-    for (int s = 21; s < 24; s++) {
-        const double v = has_asym ? tm_wave_sum(g[s]) : 0.0;
-        if (lane == 0) s_red_row[s] = v;
+    TmBfly<V, 32>::run(g, lane);
+    // lanes whose plainly-reduced low bits are zero publish; padded slots are skipped
+    constexpr int NSPLIT = (V > 16) ? 5 : (V > 8) ? 4 : (V > 4) ? 3 : (V > 2) ? 2 : 1;   // butterfly levels that split
+    const int lowmask = (64 >> NSPLIT) - 1;
+    bool valid = true;
+    const int slot = TmBfly<V, 32>::slot_of(lane, valid);
+    if ((lane & lowmask) == 0 && valid) {
+        const int dst = (slot < 3 * NC) ? slot : 21 + (slot - 3 * NC);
+        s_red_row[dst] = g[0];
     }
 }
 
-template <int K, bool GRAD>
+template <int KU, bool GRAD>
 __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
 {
-    constexpr int TB = TM_THREADS * K;
+    const int S = a.S;
+    const int TB = TM_THREADS * KU * S;
     const int tile = blockIdx.x, chain = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int base = tile * TB;
 
-    __shared__ double s_mult[TM_CHUNK * TM_MULT_DOUBLES];
-    __shared__ int s_idx[TM_CHUNK];
+    extern __shared__ double s_dyn[];
+    double *s_mult = s_dyn;                                          // [n_mult * TM_MULT_DOUBLES]
+    double *s_w = s_dyn + (size_t)a.n_mult * TM_MULT_DOUBLES;        // [TM_THREADS * KU * S]   (GRAD)
+    __shared__ int s_idx[TM_MAXMULT];
     __shared__ int s_nact;
     __shared__ double s_red[TM_WAVES][TM_GSLOTS];
 
     const TmMult *gm = a.mult + (size_t)chain * a.n_mult;
     const TmNoise *gn = a.noise + chain;
 
-    double x2[K], acc[K];
-    int bi[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int i = base + k * TM_THREADS + tid;
-        const bool valid = i < a.Nx;
-        bi[k] = valid ? i : -1;
-        x2[k] = 2.0 * a.x[valid ? i : a.Nx - 1];
-        acc[k] = 0.0;
-    }
-
-    // ---------------- pass 1: model spectrum ----------------
-    for (int c0 = 0; c0 < a.n_mult; c0 += TM_CHUNK) {
-        __syncthreads();
-        if (wave == 0) {
+    // ---------------- stage the multiplets whose window meets this tile (table order) ----------------
+    if (wave == 0) {
+        int nact = 0;
+        for (int c0 = 0; c0 < a.n_mult; c0 += 64) {
             const int j = c0 + lane;
             bool act = false;
-            if (lane < TM_CHUNK && j < a.n_mult) {
+            if (j < a.n_mult) {
                 const int imin = gm[j].imin, imax = gm[j].imax;
                 act = (imin < base + TB) && (imax > base);
             }
             const unsigned long long mask = __ballot(act);
-            if (act) s_idx[__popcll(mask & ((1ull << lane) - 1ull))] = j;
-            if (lane == 0) s_nact = __popcll(mask);
+            if (act) s_idx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+            nact += __popcll(mask);
         }
-        __syncthreads();
-        const int nact = s_nact;
-        for (int e = tid; e < nact * TM_MULT_DOUBLES; e += TM_THREADS) {
-            const int slot = e / TM_MULT_DOUBLES, f = e - slot * TM_MULT_DOUBLES;
-            s_mult[e] = reinterpret_cast<const double *>(gm + s_idx[slot])[f];
+        if (lane == 0) s_nact = nact;
+    }
+    __syncthreads();
+    const int nact = s_nact;
+    for (int e = tid; e < nact * TM_MULT_DOUBLES; e += TM_THREADS) {
+        const int slot = e / TM_MULT_DOUBLES, f = e - slot * TM_MULT_DOUBLES;
+        s_mult[e] = reinterpret_cast<const double *>(gm + s_idx[slot])[f];
+    }
+    __syncthreads();
+
+    // ---------------- per-tile noise constants ----------------
+    const int nh = gn->nh;
+    double nH[TM_MAXH], nP[TM_MAXH], nLT[TM_MAXH], nT0[TM_MAXH];
+    bool npoly = true;
+    double lxc = 0.0;
+    if (nh > 0) {
+        int ic = base + TB / 2; if (ic > a.Nx - 1) ic = a.Nx - 1;
+        int i0 = base, i1 = base + TB - 1; if (i1 > a.Nx - 1) i1 = a.Nx - 1;
+        lxc = a.lx[ic];
+        const double l0 = a.lx[i0], l1 = a.lx[i1];
+        double span = __builtin_fmax(__builtin_fabs(l0 - lxc), __builtin_fabs(l1 - lxc));
+        if (!(span == span) || !(lxc - lxc == 0.0)) npoly = false;   // log x = -inf / NaN inside the tile
+#pragma unroll
+        for (int h = 0; h < TM_MAXH; h++) {
+            nH[h] = (h < nh) ? gn->H[h] : 0.0;
+            nP[h] = (h < nh) ? gn->p[h] : 0.0;
+            nLT[h] = (h < nh) ? gn->lt[h] : 0.0;
+            if (h < nh && !(nP[h] * span <= 0.04)) npoly = false;
         }
-        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < TM_MAXH; h++) nT0[h] = (h < nh && npoly) ? exp(nP[h] * (nLT[h] + lxc)) : 0.0;
+    }
+    const bool has_gauss = gn->has_gauss != 0;
+    const double N0 = gn->N0;
+    const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
+
+    // ---------------- pass 1: model spectrum and likelihood partial sums ----------------
+    double S1 = 0.0;
+    double P = 1.0;
+    int esum = 0;
+    bool bad = false;
+    const double wscale = GRAD ? ((a.likelihood_case == 0) ? a.like_p / a.Tcoefs[chain] : 2.0 / a.Tcoefs[chain]) : 0.0;
+
+#pragma unroll 1
+    for (int u = 0; u < S; u++) {
+        double x2[KU], acc[KU];
+        int bi[KU];
+#pragma unroll
+        for (int k = 0; k < KU; k++) {
+            const int i = base + (u * KU + k) * TM_THREADS + tid;
+            const bool valid = i < a.Nx;
+            bi[k] = valid ? i : -1;
+            x2[k] = 2.0 * a.x[valid ? i : a.Nx - 1];
+            acc[k] = 0.0;
+        }
         for (int jj = 0; jj < nact; jj++) {
             const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + jj;
+            const int lo = base + u * KU * TM_THREADS;
+            if (lo + KU * TM_THREADS <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
             switch (sm->ncomp) {
-            case 1: tm_accum_mult<1, K>(sm, x2, bi, acc); break;
-            case 3: tm_accum_mult<3, K>(sm, x2, bi, acc); break;
-            case 5: tm_accum_mult<5, K>(sm, x2, bi, acc); break;
-            default: tm_accum_mult<7, K>(sm, x2, bi, acc); break;
+            case 1: tm_accum_mult<1, KU>(sm, x2, bi, acc); break;
+            case 3: tm_accum_mult<3, KU>(sm, x2, bi, acc); break;
+            case 5: tm_accum_mult<5, KU>(sm, x2, bi, acc); break;
+            default: tm_accum_mult<7, KU>(sm, x2, bi, acc); break;
             }
         }
-    }
-
-    // ---------------- noise background + Gaussian term ----------------
-    const int nh = gn->nh;
-    double lxv[K];
-    if (nh > 0) {
+        if (nh > 0) {
+            double lxv[KU];
 #pragma unroll
-        for (int k = 0; k < K; k++) lxv[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1];
-        for (int h = 0; h < nh; h++) {
-            const double H = gn->H[h], lt = gn->lt[h], p = gn->p[h];
+            for (int k = 0; k < KU; k++) lxv[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1];
+            if (npoly) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const double t = exp(p * (lt + lxv[k]));
-                acc[k] += H * (1.0 / (t + 1.0));
+                for (int h = 0; h < TM_MAXH; h++) {
+                    if (h < nh) {
+#pragma unroll
+                        for (int k = 0; k < KU; k++) {
+                            double t = nT0[h] * tm_exp_small(nP[h] * (lxv[k] - lxc));
+                            t = (t > 1e300) ? 1e300 : t;   // keeps NaN, unlike fmin
+                            acc[k] = __builtin_fma(nH[h], tm_rcp(t + 1.0), acc[k]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < TM_MAXH; h++) {
+                    if (h < nh) {
+#pragma unroll
+                        for (int k = 0; k < KU; k++) {
+                            const double t = exp(nP[h] * (nLT[h] + lxv[k]));
+                            acc[k] += nH[h] * (1.0 / (t + 1.0));
+                        }
+                    }
+                }
             }
         }
-    }
-    if (gn->has_gauss) {
-        const double gA = gn->gA, gnu0 = gn->gnu0, gs2 = gn->gs2;
+        if (has_gauss) {
+            const double gA = gn->gA, gnu0 = gn->gnu0, gs2 = gn->gs2;
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const double dd = 0.5 * x2[k] - gnu0;
-            acc[k] = gA * exp((-0.5 * (dd * dd)) / gs2) + acc[k];
+            for (int k = 0; k < KU; k++) {
+                const double dd = 0.5 * x2[k] - gnu0;
+                acc[k] = gA * exp((-0.5 * (dd * dd)) / gs2) + acc[k];
+            }
         }
-    }
-    {
-        const double N0 = gn->N0;
 #pragma unroll
-        for (int k = 0; k < K; k++) acc[k] += N0;
-    }
+        for (int k = 0; k < KU; k++) acc[k] += N0;
 
-    if (a.row_of_chain != nullptr) {
-        const int row = a.row_of_chain[chain];
         if (row >= 0) {
 #pragma unroll
-            for (int k = 0; k < K; k++)
+            for (int k = 0; k < KU; k++)
                 if (bi[k] >= 0) a.model_out[(size_t)row * a.Nx + bi[k]] = acc[k];
         }
-    }
 
-    // ---------------- likelihood partial sums ----------------
-    double S1 = 0.0, S2 = 0.0;
-    double w[K];
-    if (a.likelihood_case == 0) {
-        // -p * (sum y/M + sum log M), likelihoods.cpp:23-25
-        double P = 1.0;
-        int esum = 0;
-        bool bad = false;
-        const double scale = GRAD ? a.like_p / a.Tcoefs[chain] : 0.0;
+        if (a.likelihood_case == 0) {
+            // -p * (sum y/M + sum log M), likelihoods.cpp:23-25
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (bi[k] >= 0) {
-                const double M = acc[k];
-                const double yv = a.y[bi[k]];
-                const double rM = 1.0 / M;
-                S1 = __builtin_fma(yv, rM, S1);
+            for (int k = 0; k < KU; k++) {
+                double wv = 0.0;
+                if (bi[k] >= 0) {
+                    const double M = acc[k];
+                    const double yv = a.y[bi[k]];
+                    const bool ok = (M > 0.0) && (M < 1.7e308);
+                    bad = bad || !ok;
+                    const double rM = tm_rcp(ok ? M : 1.0);
+                    S1 = __builtin_fma(yv, rM, S1);
+                    int e;
+                    P *= frexp(ok ? M : 1.0, &e);
+                    esum += e;
+                    wv = wscale * (yv * rM * rM - rM);   // d(logL/T)/dM_i
+                }
+                if (GRAD) s_w[(u * KU + k) * TM_THREADS + tid] = wv;
+            }
+            {
                 int e;
-                P *= frexp(M, &e);
+                P = frexp(P, &e);   // keep the running mantissa product in [0.5, 1)
                 esum += e;
-                bad = bad || !(M > 0.0) || (M > 1.7e308);
-                if (GRAD) w[k] = scale * (yv * rM * rM - rM);  // d(logL/T)/dM_i
-            } else if (GRAD) {
-                w[k] = 0.0;
+            }
+        } else {
+            // -sum (y-M)^2 / sigma^2, likelihoods.cpp:36
+#pragma unroll
+            for (int k = 0; k < KU; k++) {
+                double wv = 0.0;
+                if (bi[k] >= 0) {
+                    const double dd = a.y[bi[k]] - acc[k];
+                    const double is2 = a.isig2[bi[k]];
+                    S1 = __builtin_fma(dd * dd, is2, S1);
+                    wv = wscale * dd * is2;
+                }
+                if (GRAD) s_w[(u * KU + k) * TM_THREADS + tid] = wv;
             }
         }
+    }
+    double S2 = 0.0;
+    if (a.likelihood_case == 0) {
         S2 = log(P) + (double)esum * 0.693147180559945309417232;
         if (bad) S2 = __builtin_nan("");
-    } else {
-        // -sum (y-M)^2 / sigma^2, likelihoods.cpp:36
-        const double scale = GRAD ? 1.0 / a.Tcoefs[chain] : 0.0;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (bi[k] >= 0) {
-                const double dd = a.y[bi[k]] - acc[k];
-                const double is2 = a.isig2[bi[k]];
-                S1 = __builtin_fma(dd * dd, is2, S1);
-                if (GRAD) w[k] = scale * 2.0 * dd * is2;
-            } else if (GRAD) {
-                w[k] = 0.0;
-            }
-        }
     }
     S1 = tm_wave_sum(S1);
     S2 = tm_wave_sum(S2);
-    __syncthreads();
     if (lane == 0) { s_red[wave][0] = S1; s_red[wave][1] = S2; }
     __syncthreads();
     if (tid == 0) {
@@ -308,104 +428,77 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
 
     // ---------------- pass 2: gradient partial sums ----------------
     if (GRAD) {
-        for (int c0 = 0; c0 < a.n_mult; c0 += TM_CHUNK) {
-            __syncthreads();
-            if (wave == 0) {
-                const int j = c0 + lane;
-                bool act = false;
-                if (lane < TM_CHUNK && j < a.n_mult) {
-                    const int imin = gm[j].imin, imax = gm[j].imax;
-                    act = (imin < base + TB) && (imax > base);
-                }
-                const unsigned long long mask = __ballot(act);
-                if (act) s_idx[__popcll(mask & ((1ull << lane) - 1ull))] = j;
-                if (lane == 0) s_nact = __popcll(mask);
+        for (int jj = 0; jj < nact; jj++) {
+            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + jj;
+            const int nc = sm->ncomp;
+            __syncthreads();   // s_red free (also orders s_w writes before the first read)
+            switch (nc) {
+            case 1: tm_grad_mult<1, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+            case 3: tm_grad_mult<3, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+            case 5: tm_grad_mult<5, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+            default: tm_grad_mult<7, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
             }
             __syncthreads();
-            const int nact = s_nact;
-            for (int e = tid; e < nact * TM_MULT_DOUBLES; e += TM_THREADS) {
-                const int slot = e / TM_MULT_DOUBLES, f = e - slot * TM_MULT_DOUBLES;
-                s_mult[e] = reinterpret_cast<const double *>(gm + s_idx[slot])[f];
-            }
-            __syncthreads();
-            for (int jj = 0; jj < nact; jj++) {
-                const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + jj;
-                const int nc = sm->ncomp;
-                switch (nc) {
-                case 1: tm_grad_mult<1, K>(sm, x2, bi, w, s_red[wave], lane); break;
-                case 3: tm_grad_mult<3, K>(sm, x2, bi, w, s_red[wave], lane); break;
-                case 5: tm_grad_mult<5, K>(sm, x2, bi, w, s_red[wave], lane); break;
-                default: tm_grad_mult<7, K>(sm, x2, bi, w, s_red[wave], lane); break;
-                }
-                const int nslots = 3 * nc;
-                __syncthreads();
-                if (tid < TM_GSLOTS) {
-                    double t = 0.0;
-                    if (tid < nslots || tid >= 21) {
+            if (tid < TM_GSLOTS) {
+                double t = 0.0;
+                if (tid < 3 * nc || tid >= 21) {
 #pragma unroll
-                        for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[wv][tid];
-                    }
-                    a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + s_idx[jj]) * TM_GSLOTS + tid] = t;
+                    for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[wv][tid];
                 }
-                __syncthreads();
+                a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + s_idx[jj]) * TM_GSLOTS + tid] = t;
             }
         }
         // noise terms: per Harvey k: sum w u, sum w t u^2, sum w t u^2 (lt + lx); then sum w  (u = 1/(1+t))
-        {
-            double gn_[TM_NSLOTS];
+        double gn_[TM_NSLOTS];
 #pragma unroll
-            for (int s = 0; s < TM_NSLOTS; s++) gn_[s] = 0.0;
-            for (int h = 0; h < nh; h++) {
-                const double lt = gn->lt[h], p = gn->p[h];
-                double b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        for (int s = 0; s < TM_NSLOTS; s++) gn_[s] = 0.0;
+        __syncthreads();
+#pragma unroll 1
+        for (int u = 0; u < S; u++) {
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const double arg = lt + lxv[k];
-                    const double t = exp(p * arg);
-                    const double u = 1.0 / (t + 1.0);
-                    const double wu = w[k] * u;
-                    b1 += wu;
-                    // t*u^2 -> 0 as t -> inf; written so that inf never multiplies 0
-                    const double tu2 = (t < 1.7e308) ? wu * (t * u) : 0.0;
-                    b2 += tu2;
-                    b3 = __builtin_fma(tu2, arg, b3);
+            for (int k = 0; k < KU; k++) {
+                const int i = base + (u * KU + k) * TM_THREADS + tid;
+                const int ii = i < a.Nx ? i : a.Nx - 1;
+                const double wk = s_w[(u * KU + k) * TM_THREADS + tid];   // 0 for bins beyond Nx
+                gn_[3 * TM_MAXH] += wk;
+                if (nh > 0) {
+                    const double lxk = a.lx[ii];
+#pragma unroll
+                    for (int h = 0; h < TM_MAXH; h++) {
+                        if (h < nh) {
+                            const double arg = nLT[h] + lxk;
+                            double t = npoly ? nT0[h] * tm_exp_small(nP[h] * (lxk - lxc)) : exp(nP[h] * arg);
+                            t = (t > 1e300) ? 1e300 : t;
+                            const double uu = tm_rcp(t + 1.0);
+                            const double wu = wk * uu;
+                            const double tu2 = wu * (t * uu);
+                            gn_[3 * h] += wu;
+                            gn_[3 * h + 1] += tu2;
+                            gn_[3 * h + 2] = __builtin_fma(tu2, arg, gn_[3 * h + 2]);
+                        }
+                    }
                 }
-                // compile-time slot indices (h is a runtime, wave-uniform value)
-#pragma unroll
-                for (int hh = 0; hh < TM_MAXH; hh++)
-                    if (hh == h) { gn_[3 * hh] = b1; gn_[3 * hh + 1] = b2; gn_[3 * hh + 2] = b3; }
-            }
-            double sw = 0.0;
-#pragma unroll
-            for (int k = 0; k < K; k++) sw += w[k];
-            gn_[3 * TM_MAXH] = sw;
-            if (gn->has_gauss) {
-                // Gaussian term: sum w e, sum w e d, sum w e d^2 with e = exp(-0.5 d^2/s2), d = x - nu0
-                const double gnu0 = gn->gnu0, gs2 = gn->gs2;
-                double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const double dd = 0.5 * x2[k] - gnu0;
-                    const double we = w[k] * exp((-0.5 * (dd * dd)) / gs2);
-                    e0 += we;
-                    e1 = __builtin_fma(we, dd, e1);
-                    e2 = __builtin_fma(we * dd, dd, e2);
+                if (has_gauss) {
+                    // Gaussian term: sum w e, sum w e d, sum w e d^2 with e = exp(-0.5 d^2/s2), d = x - nu0
+                    const double dd = a.x[ii] - gn->gnu0;
+                    const double we = wk * exp((-0.5 * (dd * dd)) / gn->gs2);
+                    gn_[13] += we;
+                    gn_[14] = __builtin_fma(we, dd, gn_[14]);
+                    gn_[15] = __builtin_fma(we * dd, dd, gn_[15]);
                 }
-                gn_[13] = e0; gn_[14] = e1; gn_[15] = e2;
             }
-            __syncthreads();
+        }
 #pragma unroll
-            for (int s = 0; s < TM_NSLOTS; s++) {
-                const double v = tm_wave_sum(gn_[s]);
-                if (lane == 0) s_red[wave][s] = v;
-            }
-            __syncthreads();
-            if (tid < TM_NSLOTS) {
-                double t = 0.0;
+        for (int s = 0; s < TM_NSLOTS; s++) {
+            const double v = tm_wave_sum(gn_[s]);
+            if (lane == 0) s_red[wave][s] = v;
+        }
+        __syncthreads();
+        if (tid < TM_NSLOTS) {
+            double t = 0.0;
 #pragma unroll
-                for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[wv][tid];
-                a.gnoise[((size_t)chain * a.tiles + tile) * TM_NSLOTS + tid] = t;
-            }
+            for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[wv][tid];
+            a.gnoise[((size_t)chain * a.tiles + tile) * TM_NSLOTS + tid] = t;
         }
     }
 }
@@ -437,22 +530,31 @@ __global__ __launch_bounds__(64) void tamcmc_finalize_kernel(int tiles, int like
     }
 }
 
-template <int K>
+template <int KU>
 static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
 {
     dim3 grid(a.tiles, Nchains), block(TM_THREADS);
-    if (grad) hipLaunchKernelGGL((tamcmc_eval_kernel<K, true>), grid, block, 0, stream, a);
-    else      hipLaunchKernelGGL((tamcmc_eval_kernel<K, false>), grid, block, 0, stream, a);
+    size_t lds = (size_t)a.n_mult * TM_MULT_DOUBLES * sizeof(double);
+    if (grad) lds += (size_t)TM_THREADS * KU * a.S * sizeof(double);
+    if (lds == 0) lds = 8;
+    if (lds > 48 * 1024) {
+        const void *fn = grad ? reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, true>)
+                              : reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (grad) hipLaunchKernelGGL((tamcmc_eval_kernel<KU, true>), grid, block, lds, stream, a);
+    else      hipLaunchKernelGGL((tamcmc_eval_kernel<KU, false>), grid, block, lds, stream, a);
     return (int)hipGetLastError();
 }
 
-int tm_launch_eval(const TmEvalArgs &a, int Nchains, int K, bool grad, void *stream)
+int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream)
 {
-    switch (K) {
+    if (a.n_mult > TM_MAXMULT) return (int)hipErrorInvalidValue;
+    switch (KU) {
     case 1: return tm_launch_eval_k<1>(a, Nchains, grad, (hipStream_t)stream);
     case 2: return tm_launch_eval_k<2>(a, Nchains, grad, (hipStream_t)stream);
     case 4: return tm_launch_eval_k<4>(a, Nchains, grad, (hipStream_t)stream);
-    case 8: return tm_launch_eval_k<8>(a, Nchains, grad, (hipStream_t)stream);
     default: return (int)hipErrorInvalidValue;
     }
 }

@@ -14,9 +14,12 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
 {
     const int chain = blockIdx.x;
     const int tid = threadIdx.x;
-    const double *p = params + (size_t)chain * L.Nparams;
+    extern __shared__ double s_p[];   // this chain's params row: every later access is an LDS read
+    double *p = s_p;
+    for (int e = tid; e < L.Nparams; e += 64) p[e] = params[(size_t)chain * L.Nparams + e];
     __shared__ TmChain C;
     __shared__ int s_status;
+    __syncthreads();
 
     if (tid == 0) {
         s_status = 0;
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise, void *stream)
 {
-    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(64), 0, (hipStream_t)stream, L, d_params, d_mult, d_noise);
+    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(64), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
+                       d_params, d_mult, d_noise);
     return (int)hipGetLastError();
 }
