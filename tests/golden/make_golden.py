@@ -40,7 +40,7 @@ def main():
         k = f"c{ci:02d}"
         out[k + "_id"] = np.int32(mid)
         out[k + "_plength"] = w["plength"]
-        out[k + "_x0_step_nx"] = np.array([w["x"][0], w["x"][1] - w["x"][0], w["x"].size])
+        out[k + "_x"] = w["x"]
         out[k + "_y"] = y
         out[k + "_params"] = P
         out[k + "_T"] = T

@@ -13,9 +13,7 @@ def cases():
     z = np.load(os.path.join(HERE, "golden", "oracle_regression_v1.npz"))
     for ci in range(int(z["ncases"])):
         k = f"c{ci:02d}"
-        x0, step, nx = z[k + "_x0_step_nx"]
-        x = x0 + step * np.arange(int(nx), dtype=np.float64)
-        yield dict(id=int(z[k + "_id"]), plength=z[k + "_plength"], x=x, y=z[k + "_y"], P=z[k + "_params"], T=z[k + "_T"],
+        yield dict(id=int(z[k + "_id"]), plength=z[k + "_plength"], x=z[k + "_x"], y=z[k + "_y"], P=z[k + "_params"], T=z[k + "_T"],
                    logL=z[k + "_logL"], status=z[k + "_status"], probe=z[k + "_probe"], mprobe=z[k + "_model_probe"])
 
 
