@@ -31,7 +31,8 @@ class AccelError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libtamcmc_accel.so")
+    """In-tree library; TAMCMC_ACCEL_LIB overrides it (developer knob for A/B builds)."""
+    return os.environ.get("TAMCMC_ACCEL_LIB") or os.path.join(_HERE, "libtamcmc_accel.so")
 
 
 def load_library():

@@ -66,6 +66,9 @@ struct TmNoise {
     int32_t pad;
 };
 
+static_assert(sizeof(TmNoise) == 144, "TmNoise layout");
+#define TM_NOISE_DOUBLES 18
+
 struct TmEvalArgs {
     const double *x, *y, *lx, *isig2;
     const TmMult *mult;

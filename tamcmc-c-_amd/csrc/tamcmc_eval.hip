@@ -138,7 +138,7 @@ __device__ __forceinline__ double tm_mult_value(double x2, const double (&nu2)[N
 }
 
 // Forward: add multiplet `sm` (LDS) to acc[] for KU bins.
-template <int NC, int KU>
+template <int NC, int KU, bool ASYM>
 __device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x2)[KU], const int (&bi)[KU], double (&acc)[KU])
 {
     double nu2[NC], hq[NC];
@@ -146,13 +146,12 @@ __device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x
     for (int m = 0; m < NC; m++) { nu2[m] = sm->nu2[m]; hq[m] = sm->hq[m]; }
     const double g2 = sm->g2;
     const int imin = sm->imin, imax = sm->imax;
-    const bool has_asym = sm->has_asym != 0;
-    const double aAh = 0.5 * sm->aA, aB = sm->aB, c2 = sm->c2;
+    const double aAh = ASYM ? 0.5 * sm->aA : 0.0, aB = ASYM ? sm->aB : 1.0, c2 = ASYM ? sm->c2 : 0.0;
 #pragma unroll
     for (int k = 0; k < KU; k++) {
         double d[NC], r[NC];
         double s = tm_mult_value<NC>(x2[k], nu2, hq, g2, d, r);
-        if (has_asym) {
+        if (ASYM) {
             const double a = __builtin_fma(x2[k], aAh, aB);
             s = s * __builtin_fma(a, a, c2);
         }
@@ -165,19 +164,18 @@ __device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x
 // the wave and leave the wave totals in s_red_row[slot].
 //   g[3m+0] = sum wA r_m, g[3m+1] = sum wA d_m r_m^2, g[3m+2] = sum wA r_m^2   (d = 2x - 2nu, r = 1/E)
 //   g[3NC..3NC+2] = sum w S, sum w S a, sum w S a x   (S = un-asymmetrised multiplet sum; zero if asym == 0)
-template <int NC, int KU>
+template <int NC, int KU, bool ASYM>
 __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__restrict__ gx, const double *s_w,
                                              int base, int S, int Nx, int tid, int lane, double *s_red_row)
 {
-    constexpr int V = 3 * NC + 3;
+    constexpr int V = ASYM ? 3 * NC + 3 : 3 * NC;
     double g[TM_GSLOTS];
     double nu2[NC], hq[NC];
 #pragma unroll
     for (int m = 0; m < NC; m++) { nu2[m] = sm->nu2[m]; hq[m] = sm->hq[m]; }
     const double g2 = sm->g2;
     const int imin = sm->imin, imax = sm->imax;
-    const bool has_asym = sm->has_asym != 0;
-    const double aAh = 0.5 * sm->aA, aB = sm->aB, c2 = sm->c2;
+    const double aAh = ASYM ? 0.5 * sm->aA : 0.0, aB = ASYM ? sm->aB : 1.0, c2 = ASYM ? sm->c2 : 0.0;
 #pragma unroll
     for (int s = 0; s < TM_GSLOTS; s++) g[s] = 0.0;
 #pragma unroll 1
@@ -194,7 +192,7 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__r
             double d[NC], r[NC];
             const double Sv = tm_mult_value<NC>(x2, nu2, hq, g2, d, r);
             double wA = wk;
-            if (has_asym) {
+            if (ASYM) {
                 const double a = __builtin_fma(x2, aAh, aB);
                 wA = wk * __builtin_fma(a, a, c2);
                 const double ws = wk * Sv;
@@ -224,8 +222,14 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__r
     }
 }
 
+#ifndef TM_LB_FWD
+#define TM_LB_FWD 4    // resident waves per SIMD the register allocator must allow (likelihood-only kernel)
+#endif
+#ifndef TM_LB_GRAD
+#define TM_LB_GRAD 2   // same for the gradient kernel
+#endif
 template <int KU, bool GRAD>
-__global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
+__global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
 {
     const int S = a.S;
     const int TB = TM_THREADS * KU * S;
@@ -238,59 +242,64 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
     double *s_w = s_dyn + (size_t)a.n_mult * TM_MULT_DOUBLES;        // [TM_THREADS * KU * S]   (GRAD)
     __shared__ int s_idx[TM_MAXMULT];
     __shared__ int s_nact;
+    __shared__ int s_flags[2];
+    __shared__ double s_lxc;
+    __shared__ double s_t0[TM_MAXH];
+    __shared__ double s_noise[TM_NOISE_DOUBLES];
     __shared__ double s_red[TM_WAVES][TM_GSLOTS];
 
     const TmMult *gm = a.mult + (size_t)chain * a.n_mult;
     const TmNoise *gn = a.noise + chain;
 
-    // ---------------- stage the multiplets whose window meets this tile (table order) ----------------
+    // ---------------- prologue: one global round trip ----------------
+    // The chain's whole multiplet table (160 B each) and noise record go to LDS with coalesced loads;
+    // the list of multiplets whose window meets this tile is then built from LDS (ballot, table order).
+    for (int e = tid; e < a.n_mult * TM_MULT_DOUBLES; e += TM_THREADS) s_mult[e] = reinterpret_cast<const double *>(gm)[e];
+    if (tid < TM_NOISE_DOUBLES) s_noise[tid] = reinterpret_cast<const double *>(gn)[tid];
+    double lx_c = 0.0, lx_0 = 0.0, lx_1 = 0.0;
+    if (tid < 4) {
+        int ic = base + TB / 2; if (ic > a.Nx - 1) ic = a.Nx - 1;
+        int i1 = base + TB - 1; if (i1 > a.Nx - 1) i1 = a.Nx - 1;
+        lx_c = a.lx[ic]; lx_0 = a.lx[base]; lx_1 = a.lx[i1];
+    }
+    __syncthreads();
+    const TmNoise *sn = reinterpret_cast<const TmNoise *>(s_noise);
+    const int nh = sn->nh;
     if (wave == 0) {
         int nact = 0;
         for (int c0 = 0; c0 < a.n_mult; c0 += 64) {
             const int j = c0 + lane;
             bool act = false;
             if (j < a.n_mult) {
-                const int imin = gm[j].imin, imax = gm[j].imax;
-                act = (imin < base + TB) && (imax > base);
+                const TmMult *m = reinterpret_cast<const TmMult *>(s_mult) + j;
+                act = (m->imin < base + TB) && (m->imax > base);
             }
             const unsigned long long mask = __ballot(act);
             if (act) s_idx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = j;
             nact += __popcll(mask);
         }
         if (lane == 0) s_nact = nact;
+        // per-tile Harvey constants: t0_h = (1e-3 tau x_c)^p; polynomial path valid if |p (log x - log x_c)| <= 0.04
+        if (lane < 4) {
+            const double span = __builtin_fmax(__builtin_fabs(lx_0 - lx_c), __builtin_fabs(lx_1 - lx_c));
+            bool ok = (span == span) && (lx_c - lx_c == 0.0);
+            double t0 = 0.0;
+            if (lane < nh) {
+                ok = ok && (sn->p[lane] * span <= 0.04);
+                t0 = exp(sn->p[lane] * (sn->lt[lane] + lx_c));
+                ok = ok && (t0 < 1e290);
+                s_t0[lane] = t0;
+            }
+            const unsigned long long okm = __ballot(ok);
+            if (lane == 0) { s_flags[0] = ((okm & 0xFull) == 0xFull) ? 1 : 0; s_lxc = lx_c; }
+        }
     }
     __syncthreads();
     const int nact = s_nact;
-    for (int e = tid; e < nact * TM_MULT_DOUBLES; e += TM_THREADS) {
-        const int slot = e / TM_MULT_DOUBLES, f = e - slot * TM_MULT_DOUBLES;
-        s_mult[e] = reinterpret_cast<const double *>(gm + s_idx[slot])[f];
-    }
-    __syncthreads();
-
-    // ---------------- per-tile noise constants ----------------
-    const int nh = gn->nh;
-    double nH[TM_MAXH], nP[TM_MAXH], nLT[TM_MAXH], nT0[TM_MAXH];
-    bool npoly = true;
-    double lxc = 0.0;
-    if (nh > 0) {
-        int ic = base + TB / 2; if (ic > a.Nx - 1) ic = a.Nx - 1;
-        int i0 = base, i1 = base + TB - 1; if (i1 > a.Nx - 1) i1 = a.Nx - 1;
-        lxc = a.lx[ic];
-        const double l0 = a.lx[i0], l1 = a.lx[i1];
-        double span = __builtin_fmax(__builtin_fabs(l0 - lxc), __builtin_fabs(l1 - lxc));
-        if (!(span == span) || !(lxc - lxc == 0.0)) npoly = false;   // log x = -inf / NaN inside the tile
-#pragma unroll
-        for (int h = 0; h < TM_MAXH; h++) {
-            nH[h] = (h < nh) ? gn->H[h] : 0.0;
-            nP[h] = (h < nh) ? gn->p[h] : 0.0;
-            nLT[h] = (h < nh) ? gn->lt[h] : 0.0;
-            if (h < nh && !(nP[h] * span <= 0.04)) npoly = false;
-        }
-#pragma unroll
-        for (int h = 0; h < TM_MAXH; h++) nT0[h] = (h < nh && npoly) ? exp(nP[h] * (nLT[h] + lxc)) : 0.0;
-    }
-    const bool has_gauss = gn->has_gauss != 0;
-    const double N0 = gn->N0;
+    const bool npoly = s_flags[0] != 0;
+    const double lxc = s_lxc;
+    const bool has_gauss = sn->has_gauss != 0;
+    const double N0 = sn->N0;
     const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
 
     // ---------------- pass 1: model spectrum and likelihood partial sums ----------------
@@ -313,47 +322,53 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
             acc[k] = 0.0;
         }
         for (int jj = 0; jj < nact; jj++) {
-            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + jj;
+            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + s_idx[jj];
             const int lo = base + u * KU * TM_THREADS;
             if (lo + KU * TM_THREADS <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
-            switch (sm->ncomp) {
-            case 1: tm_accum_mult<1, KU>(sm, x2, bi, acc); break;
-            case 3: tm_accum_mult<3, KU>(sm, x2, bi, acc); break;
-            case 5: tm_accum_mult<5, KU>(sm, x2, bi, acc); break;
-            default: tm_accum_mult<7, KU>(sm, x2, bi, acc); break;
+            if (sm->has_asym) {
+                switch (sm->ncomp) {
+                case 1: tm_accum_mult<1, KU, true>(sm, x2, bi, acc); break;
+                case 3: tm_accum_mult<3, KU, true>(sm, x2, bi, acc); break;
+                case 5: tm_accum_mult<5, KU, true>(sm, x2, bi, acc); break;
+                default: tm_accum_mult<7, KU, true>(sm, x2, bi, acc); break;
+                }
+            } else {
+                switch (sm->ncomp) {
+                case 1: tm_accum_mult<1, KU, false>(sm, x2, bi, acc); break;
+                case 3: tm_accum_mult<3, KU, false>(sm, x2, bi, acc); break;
+                case 5: tm_accum_mult<5, KU, false>(sm, x2, bi, acc); break;
+                default: tm_accum_mult<7, KU, false>(sm, x2, bi, acc); break;
+                }
             }
         }
         if (nh > 0) {
-            double lxv[KU];
+            double dl[KU];
 #pragma unroll
-            for (int k = 0; k < KU; k++) lxv[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1];
+            for (int k = 0; k < KU; k++) dl[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1];
             if (npoly) {
 #pragma unroll
-                for (int h = 0; h < TM_MAXH; h++) {
-                    if (h < nh) {
+                for (int k = 0; k < KU; k++) dl[k] -= lxc;
+                for (int h = 0; h < nh; h++) {
+                    const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
 #pragma unroll
-                        for (int k = 0; k < KU; k++) {
-                            double t = nT0[h] * tm_exp_small(nP[h] * (lxv[k] - lxc));
-                            t = (t > 1e300) ? 1e300 : t;   // keeps NaN, unlike fmin
-                            acc[k] = __builtin_fma(nH[h], tm_rcp(t + 1.0), acc[k]);
-                        }
+                    for (int k = 0; k < KU; k++) {
+                        const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
+                        acc[k] = __builtin_fma(Hh, tm_rcp(t + 1.0), acc[k]);
                     }
                 }
             } else {
+                for (int h = 0; h < nh; h++) {
+                    const double Hh = sn->H[h], ph = sn->p[h], lth = sn->lt[h];
 #pragma unroll
-                for (int h = 0; h < TM_MAXH; h++) {
-                    if (h < nh) {
-#pragma unroll
-                        for (int k = 0; k < KU; k++) {
-                            const double t = exp(nP[h] * (nLT[h] + lxv[k]));
-                            acc[k] += nH[h] * (1.0 / (t + 1.0));
-                        }
+                    for (int k = 0; k < KU; k++) {
+                        const double t = exp(ph * (lth + dl[k]));
+                        acc[k] += Hh * (1.0 / (t + 1.0));
                     }
                 }
             }
         }
         if (has_gauss) {
-            const double gA = gn->gA, gnu0 = gn->gnu0, gs2 = gn->gs2;
+            const double gA = sn->gA, gnu0 = sn->gnu0, gs2 = sn->gs2;
 #pragma unroll
             for (int k = 0; k < KU; k++) {
                 const double dd = 0.5 * x2[k] - gnu0;
@@ -429,14 +444,24 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
     // ---------------- pass 2: gradient partial sums ----------------
     if (GRAD) {
         for (int jj = 0; jj < nact; jj++) {
-            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + jj;
+            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + s_idx[jj];
             const int nc = sm->ncomp;
             __syncthreads();   // s_red free (also orders s_w writes before the first read)
-            switch (nc) {
-            case 1: tm_grad_mult<1, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-            case 3: tm_grad_mult<3, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-            case 5: tm_grad_mult<5, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-            default: tm_grad_mult<7, KU>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+            if (sm->has_asym) {
+                switch (nc) {
+                case 1: tm_grad_mult<1, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                case 3: tm_grad_mult<3, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                case 5: tm_grad_mult<5, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                default: tm_grad_mult<7, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                }
+            } else {
+                if (lane == 0) { s_red[wave][21] = 0.0; s_red[wave][22] = 0.0; s_red[wave][23] = 0.0; }
+                switch (nc) {
+                case 1: tm_grad_mult<1, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                case 3: tm_grad_mult<3, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                case 5: tm_grad_mult<5, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                default: tm_grad_mult<7, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                }
             }
             __syncthreads();
             if (tid < TM_GSLOTS) {
@@ -466,8 +491,9 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
 #pragma unroll
                     for (int h = 0; h < TM_MAXH; h++) {
                         if (h < nh) {
-                            const double arg = nLT[h] + lxk;
-                            double t = npoly ? nT0[h] * tm_exp_small(nP[h] * (lxk - lxc)) : exp(nP[h] * arg);
+                            const double ph = sn->p[h];
+                            const double arg = sn->lt[h] + lxk;
+                            double t = npoly ? s_t0[h] * tm_exp_small(ph * (lxk - lxc)) : exp(ph * arg);
                             t = (t > 1e300) ? 1e300 : t;
                             const double uu = tm_rcp(t + 1.0);
                             const double wu = wk * uu;
@@ -480,8 +506,8 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_eval_kernel(TmEvalArgs a)
                 }
                 if (has_gauss) {
                     // Gaussian term: sum w e, sum w e d, sum w e d^2 with e = exp(-0.5 d^2/s2), d = x - nu0
-                    const double dd = a.x[ii] - gn->gnu0;
-                    const double we = wk * exp((-0.5 * (dd * dd)) / gn->gs2);
+                    const double dd = a.x[ii] - sn->gnu0;
+                    const double we = wk * exp((-0.5 * (dd * dd)) / sn->gs2);
                     gn_[13] += we;
                     gn_[14] = __builtin_fma(we, dd, gn_[14]);
                     gn_[15] = __builtin_fma(we * dd, dd, gn_[15]);
