@@ -46,7 +46,7 @@ def main():
 
     import torch
     import tamcmc_amd
-    from tamcmc_amd import synth
+    from tamcmc_amd import shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -68,7 +68,7 @@ def main():
     total_chains = nchains * world
     P_all = synth.chain_params(w, total_chains)
     T_all = synth.temperatures(total_chains)
-    sl = slice(rank * nchains, (rank + 1) * nchains)       # contiguous in temperature
+    sl = shard.chain_slice(rank, world, nchains)           # contiguous in temperature
     with tamcmc_amd.Accel(2, w["plength"], w["x"], np.ones(args.nx), device_id=local) as a0:
         m_true, st = a0.model_explicit(w["params_true"])   # product path builds the synthetic truth
     assert st == 0
@@ -89,27 +89,9 @@ def main():
         acc.eval_batch_device(nchains, d_params.data_ptr(), d_T.data_ptr(), d_logL.data_ptr(),
                               d_grad.data_ptr() if grad else 0, d_status.data_ptr())
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
     def timed(n, grad):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step(grad)
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        # barrier + synchronize on both sides, exactly n steps, MAX over ranks (tests/test_shard_gloo.py)
+        return shard.timed_loop(lambda: step(grad), n, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
 
     for _ in range(args.warmup):
         step(True)

@@ -47,6 +47,7 @@ struct tamcmc_ctx {
     int32_t *d_status = nullptr, *d_rows = nullptr;
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
+    void *d_chain_rec = nullptr, *d_aux = nullptr;   // TmChain / TmMultFull records kept for the backward kernel
     double *d_model = nullptr;
     size_t model_cap = 0;
     // variables
@@ -144,6 +145,7 @@ static void free_batch(tamcmc_ctx *c)
     (void)hipFree(c->d_params); (void)hipFree(c->d_T); (void)hipFree(c->d_logL); (void)hipFree(c->d_part);
     (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad);
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
+    (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
     c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = nullptr;
     c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
     c->cap = 0; c->cap_grad = false;
@@ -171,6 +173,8 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
         TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g * TM_NSLOTS * sizeof(double)));
         const int nv = c->Nvars > 0 ? c->Nvars : 1;
         TM_HIP(hipMalloc(&c->d_grad, n * nv * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_chain_rec, n * tm_sizeof_chain_rec()));
+        TM_HIP(hipMalloc(&c->d_aux, n * nm * tm_sizeof_aux()));
     }
     c->cap = cap;
     c->cap_grad = g;
@@ -338,7 +342,8 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int K = grad ? c->Kg : c->K;
     const int S = grad ? c->Sg : c->S;
     const int tiles = grad ? c->tiles_g : c->tiles;
-    int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_mult, c->d_noise, c->stream);
+    int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_mult, c->d_noise, grad ? c->d_chain_rec : nullptr,
+                             grad ? c->d_aux : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
@@ -362,11 +367,13 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
         TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
     }
-    rc = tm_launch_finalize(c->L, Nchains, tiles, c->d_part, c->d_noise, d_T, d_logL, d_status, c->stream);
-    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "finalize launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
-    if (grad) {
-        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, d_T, c->d_mult, c->d_gmult,
-                                c->d_gnoise, c->Nvars, c->d_relax, d_grad, c->stream);
+    if (!grad) {
+        rc = tm_launch_finalize(c->L, Nchains, tiles, c->d_part, c->d_noise, d_T, d_logL, d_status, c->stream);
+        if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "finalize launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    } else {
+        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, d_T, c->d_chain_rec, c->d_aux,
+                                c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->Nvars, c->d_relax, d_grad, d_logL,
+                                d_status, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }
     return TAMCMC_OK;

@@ -4,12 +4,15 @@
 // CPU oracle's log-likelihood only ("parity unpinned").  The truncation window [imin,imax) moves
 // with the parameters; like any analytic gradient of a truncated model this ignores the motion.
 //
-// One workgroup (one wave) per chain.  Phase 1: lane j re-derives multiplet j (tamcmc_derive.h),
-// sums its partials over the tiles its window touches IN TILE ORDER, and emits (param index, value)
-// pairs plus chain-level adjoints into LDS.  Phase 2: lane 0 turns the chain-level adjoints
-// (splitting, inclination, visibilities, asymmetry, numax, noise) into more pairs.  Phase 3: lane k
-// gathers, in pair order, everything addressed to variable k.  No atomics: bitwise reproducible.
-// Compiled with -ffp-contract=off because it shares tamcmc_derive.h with the setup kernel.
+// One workgroup (256 threads) per chain.  The chain record (TmChain) and the per-multiplet records
+// (TmMultFull) written by the setup kernel are read back instead of being re-derived.
+// Phase 0: wave 3 sums the likelihood partials (the finalize step: logL, status); lanes 64..79 sum the
+// noise partials.  Phase 1: thread j sums multiplet j's partials over the tiles its window touches IN
+// TILE ORDER and emits (param index, value) pairs plus chain-level adjoints into LDS.  Phase 2: the
+// chain-level adjoints are summed over multiplets (one thread per slot, multiplet order) and thread 0
+// turns them (splitting, inclination, visibilities, asymmetry, numax, noise) into more pairs.
+// Phase 3: thread k gathers, in pair order, everything addressed to variable k.
+// No atomics: bitwise reproducible.  Compiled with -ffp-contract=off like the setup TU.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
 #include "tamcmc_derive.h"
@@ -36,17 +39,23 @@ __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 
 __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int TB,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
-                                                             const TmMult *__restrict__ mult,
+                                                             const TmChain *__restrict__ chain_rec,
+                                                             const TmMultFull *__restrict__ aux,
+                                                             const TmNoise *__restrict__ noise,
+                                                             const double *__restrict__ part,
                                                              const double *__restrict__ gmult,
                                                              const double *__restrict__ gnoise,
                                                              int Nvars, const int32_t *__restrict__ relax,
-                                                             double *__restrict__ grad)
+                                                             double *__restrict__ grad,
+                                                             double *__restrict__ logL, int32_t *__restrict__ status,
+                                                             int aux_in_lds)
 {
     const double PI = 3.141592653589793238462643383279502884;
     const int chain = blockIdx.x, tid = threadIdx.x;
     extern __shared__ double s_dyn[];
     __shared__ TmChain C;
     __shared__ double s_gn[TM_NSLOTS];
+    __shared__ double s_S[TM_NSHARED];
     const int nm = L.n_mult;
     // dynamic LDS carve-up: the chain's params row first (every later access is an LDS read)
     double *p = s_dyn;                                         // [Nparams]
@@ -55,12 +64,23 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
-    int *pair_idx = reinterpret_cast<int *>(shared_adj + (size_t)nm * TM_NSHARED);  // [npairs_max]
+    double *s_G = shared_adj + (size_t)nm * TM_NSHARED;        // [nm*TM_GSLOTS] tile-summed partials
+    double *s_adjh = s_G + (size_t)nm * TM_GSLOTS;             // [nm*TM_MAXM]
+    int *pair_idx = reinterpret_cast<int *>(s_adjh + (size_t)nm * TM_MAXM);  // [npairs_max]
+    // per-multiplet records: staged in LDS when they fit (coalesced copy), else read in place from global
+    constexpr int AUXD = (int)(sizeof(TmMultFull) / sizeof(double));
+    double *s_aux = reinterpret_cast<double *>(pair_idx + ((npairs_max + 1) & ~1));
+    const TmMultFull *auxp = aux + (size_t)chain * nm;
+    if (aux_in_lds) {
+        for (int e = tid; e < nm * AUXD; e += TM_BW_THREADS) s_aux[e] = reinterpret_cast<const double *>(auxp)[e];
+        auxp = reinterpret_cast<const TmMultFull *>(s_aux);
+    }
 
     for (int e = tid; e < npairs_max; e += TM_BW_THREADS) { pair_idx[e] = -1; pair_val[e] = 0.0; }
     for (int e = tid; e < nm * TM_NSHARED; e += TM_BW_THREADS) shared_adj[e] = 0.0;
-    __syncthreads();
-    if (tid == 0 && L.family != TM_FAM_GAUSS) tm_derive_chain(L, p, C);
+    if (L.family != TM_FAM_GAUSS)
+        for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_BW_THREADS)
+            reinterpret_cast<double *>(&C)[e] = reinterpret_cast<const double *>(chain_rec + chain)[e];
     // noise partials: one lane per slot, tiles in order (independent loads, pipelined)
     if (tid >= 64 && tid < 64 + TM_NSLOTS) {
         const int sl = tid - 64;
@@ -68,29 +88,52 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         for (int t = 0; t < tiles; t++) acc += gnoise[((size_t)chain * tiles + t) * TM_NSLOTS + sl];
         s_gn[sl] = acc;
     }
+    // finalize (same arithmetic and order as tamcmc_finalize_kernel): wave 3
+    if (tid >= 192) {
+        const int lane = tid - 192;
+        const double *pp = part + (size_t)chain * tiles * 2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = lane; t < tiles; t += 64) { s1 += pp[2 * t]; s2 += pp[2 * t + 1]; }
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+        if (lane == 0) {
+            double f = (L.likelihood_case == 0) ? -L.like_p * (s1 + s2) : -s1;
+            f = f / Tcoefs[chain];
+            int st = noise[chain].status;
+            if (st != 0) f = __builtin_nan("");
+            else if (!(f == f)) st = 1;
+            logL[chain] = f;
+            if (status) status[chain] = st;
+        }
+    }
     __syncthreads();
 
     // ---------------- phase 1: per multiplet ----------------
+    // phase 1a: every (multiplet, slot) pair sums its tile partials in tile order -- all threads, LDS result
+    for (int item = tid; item < nm * TM_GSLOTS; item += TM_BW_THREADS) {
+        const int j = item / TM_GSLOTS, sl = item - j * TM_GSLOTS;
+        const TmMultFull &M = auxp[j];
+        double acc = 0.0;
+        if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
+            const int t0 = M.imin / TB, t1 = (M.imax - 1) / TB;
+            for (int t = t0; t <= t1 && t < tiles; t++)
+                acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
+        }
+        s_G[item] = acc;
+    }
+    __syncthreads();
+    // phase 1b: chain rule, one thread per multiplet (records read in place: no private arrays -> no scratch)
     for (int j = tid; j < nm; j += TM_BW_THREADS) {
-        TmMultFull M;
-        tm_derive_mult(L, C, p, j, M);
+        const TmMultFull &M = auxp[j];
         double *sh = shared_adj + (size_t)j * TM_NSHARED;
         int *pi = pair_idx + j * TM_NPAIR;
         double *pv = pair_val + j * TM_NPAIR;
         int np = 0;
         if (M.status != 0) continue;
-        double G[TM_GSLOTS];
-        for (int s = 0; s < TM_GSLOTS; s++) G[s] = 0.0;
-        const int t0 = M.imin / TB, t1 = (M.imax - 1) / TB;
-        for (int t = t0; t <= t1 && t < tiles; t++) {
-            const double *g = gmult + (((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS;
-            for (int s = 0; s < 3 * M.ncomp; s++) G[s] += g[s];
-            for (int s = 21; s < 24; s++) G[s] += g[s];
-        }
+        const double *G = s_G + (size_t)j * TM_GSLOTS;
+        double *adj_h = s_adjh + (size_t)j * TM_MAXM;
         const int l = M.l;
         const double W = M.W, g2 = W * W, f = M.f;
         double adj_g2 = 0.0, adj_f = 0.0, adj_W = 0.0, adj_fs = 0.0;
-        double adj_h[TM_MAXM];
         for (int k = 0; k < M.ncomp; k++) {
             const double hq = M.h[k] * g2;
             const double adj_hq = G[3 * k];
@@ -205,16 +248,19 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     }
     __syncthreads();
 
-    // ---------------- phase 2: chain-level adjoints and noise (lane 0) ----------------
+    // ---------------- phase 2: chain-level adjoints and noise ----------------
+    if (tid < TM_NSHARED) {
+        double acc = 0.0;
+        for (int j = 0; j < nm; j++) acc += shared_adj[(size_t)j * TM_NSHARED + tid];   // multiplet order
+        s_S[tid] = acc;
+    }
+    __syncthreads();
     if (tid == 0) {
         int *pi = pair_idx + nm * TM_NPAIR;
         double *pv = pair_val + nm * TM_NPAIR;
         int np = 0;
         if (L.family != TM_FAM_GAUSS) {
-            double S[TM_NSHARED];
-            for (int s = 0; s < TM_NSHARED; s++) S[s] = 0.0;
-            for (int j = 0; j < nm; j++)
-                for (int s = 0; s < TM_NSHARED; s++) S[s] += shared_adj[(size_t)j * TM_NSHARED + s];
+            const double *S = s_S;
             const int id = L.model_case, s0 = L.s, q = L.q;
             pi[np] = s0 + 1; pv[np] = S[SL_ETA]; np++;
             pi[np] = s0 + 2; pv[np] = S[SL_A3]; np++;
@@ -305,14 +351,19 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 }
 
 int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
-                       const double *d_Tcoefs, const TmMult *d_mult, const double *d_gmult, const double *d_gnoise,
-                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, void *stream)
+                       const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
+                       const double *d_part, const double *d_gmult, const double *d_gnoise,
+                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
+                       void *stream)
 {
     const int nm = L.n_mult;
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
-    const size_t lds = (size_t)L.Nparams * sizeof(double) + (size_t)npairs_max * sizeof(double) +
-                       (size_t)nm * TM_NSHARED * sizeof(double) + (size_t)npairs_max * sizeof(int);
+    size_t lds = (size_t)L.Nparams * sizeof(double) + (size_t)npairs_max * sizeof(double) +
+                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + (size_t)((npairs_max + 1) & ~1) * sizeof(int);
+    const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);
+    const int aux_in_lds = (lds + aux_bytes <= 100 * 1024) ? 1 : 0;
+    if (aux_in_lds) lds += aux_bytes;
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tamcmc_backward_kernel),
@@ -320,6 +371,8 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_t
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
-                       bins_per_tile, d_params, d_Tcoefs, d_mult, d_gmult, d_gnoise, Nvars, d_index_to_relax, d_grad);
+                       bins_per_tile, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
+                       static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, Nvars,
+                       d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();
 }

@@ -32,6 +32,8 @@ struct TmChain {
     int32_t use_ratios;             // 1: heights = H*ratios (variants 0, 1); 0: heights per m from params
 };
 
+static_assert(sizeof(TmChain) % sizeof(double) == 0, "TmChain is copied as doubles");
+
 struct TmMultFull {
     int32_t n, l, ncomp;
     int32_t idx_f;                  // params index of the mode frequency
@@ -48,6 +50,8 @@ struct TmMultFull {
     int32_t imin, imax, status;
 };
 
+static_assert(sizeof(TmMultFull) % sizeof(double) == 0, "TmMultFull is copied as doubles");
+
 __device__ __forceinline__ double tm_ipow(double b, int e)
 {
     double r = 1.0;
@@ -57,9 +61,9 @@ __device__ __forceinline__ double tm_ipow(double b, int e)
 
 __device__ __forceinline__ int tm_factorial(int n)
 {
-    int f = 1;
-    for (int i = 2; i <= n; i++) f = f * i;
-    return f;
+    // n <= 6 on this path (l <= 3); a table avoids the serial multiply loops of function_rot.cpp:99-106
+    const int t = (n <= 1) ? 1 : (n == 2) ? 2 : (n == 3) ? 6 : (n == 4) ? 24 : (n == 5) ? 120 : 720;
+    return t;
 }
 
 // d^l_{m1,m2}(beta) and its derivative with respect to beta (radians); function_rot.cpp:81-93
@@ -164,8 +168,8 @@ __device__ inline int tm_window(const TmLayout &L, double fc_l, double f_s, doub
     return 0;
 }
 
-// Chain-level quantities.  p = this chain's params row.
-__device__ inline void tm_derive_chain(const TmLayout &L, const double *p, TmChain &C)
+// Chain-level scalars (everything but the inclination -> m-ratio tables).  p = this chain's params row.
+__device__ inline void tm_derive_chain_scalars(const TmLayout &L, const double *p, TmChain &C)
 {
     const double PI_L = 3.141592653589793238462643383279502884; // the reference's pi is long double; fp64 on the device
     const int id = L.model_case;
@@ -202,11 +206,6 @@ __device__ inline void tm_derive_chain(const TmLayout &L, const double *p, TmCha
         C.ratios[3][0] = fabs(p[q + 8]); C.ratios[3][1] = fabs(p[q + 7]); C.ratios[3][2] = fabs(p[q + 6]);
         C.ratios[3][3] = fabs(p[q + 5]); C.ratios[3][4] = fabs(p[q + 6]); C.ratios[3][5] = fabs(p[q + 7]);
         C.ratios[3][6] = fabs(p[q + 8]);
-    } else if (L.variant != 2) {
-        for (int l = 1; l <= 3; l++) {
-            const bool need = (L.family == TM_FAM_GLOBAL) ? (L.lmax >= l) : (L.Nfl[l] >= 1);
-            if (need) tm_ratios(l, C.inc, C.ratios[l], C.dratios[l]);
-        }
     }
     if (id == 9) {
         // models.cpp:1372-1390
@@ -222,6 +221,32 @@ __device__ inline void tm_derive_chain(const TmLayout &L, const double *p, TmCha
         C.Htot = Htot;
         C.numax = numax / Htot;
     }
+}
+
+// m-height ratios from the inclination: nine (l, |m|) entries, one per lane (lanes 0..8), in parallel.
+__device__ inline void tm_derive_chain_ratios(const TmLayout &L, TmChain &C, int lane)
+{
+    if (L.model_case == 12 || L.variant == 2 || lane >= 9) return;
+    const int l = (lane < 2) ? 1 : (lane < 5) ? 2 : 3;
+    const int am = (lane < 2) ? lane : (lane < 5) ? lane - 2 : lane - 5;
+    const bool need = (L.family == TM_FAM_GLOBAL) ? (L.lmax >= l) : (L.Nfl[l] >= 1);
+    if (!need) return;
+    const double PI = 3.141592653589793238462643;
+    const double angle = PI * C.inc / 180.;
+    double dv;
+    const double v = tm_dmm(l, am, 0, angle, &dv);
+    const double r = v * v, dr = 2.0 * v * dv * (PI / 180.);
+    C.ratios[l][l + am] = r; C.ratios[l][l - am] = r;
+    C.dratios[l][l + am] = dr; C.dratios[l][l - am] = dr;
+}
+
+// Cooperative derivation by a whole workgroup (C in LDS).  Contains barriers: call from uniform code.
+__device__ inline void tm_derive_chain_coop(const TmLayout &L, const double *p, TmChain &C, int tid)
+{
+    if (tid == 0) tm_derive_chain_scalars(L, p, C);
+    __syncthreads();
+    tm_derive_chain_ratios(L, C, tid);
+    __syncthreads();
 }
 
 // (n, l) of multiplet j and the offset of degree l's block in local layouts

@@ -88,12 +88,18 @@ struct TmEvalArgs {
 extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise, void *stream);
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise,
+                    void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, void *stream);
+size_t tm_sizeof_chain_rec();
+size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
 int tm_launch_finalize(const TmLayout &L, int Nchains, int tiles, const double *d_part, const TmNoise *d_noise,
                        const double *d_Tcoefs, double *d_logL, int32_t *d_status, void *stream);
+// backward also performs the finalize step (logL, status) of the gradient path
 int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
-                       const double *d_Tcoefs, const TmMult *d_mult, const double *d_gmult, const double *d_gnoise,
-                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, void *stream);
+                       const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
+                       const double *d_part, const double *d_gmult, const double *d_gnoise,
+                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
+                       void *stream);
 }
 #endif

@@ -226,7 +226,7 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__r
 #define TM_LB_FWD 4    // resident waves per SIMD the register allocator must allow (likelihood-only kernel)
 #endif
 #ifndef TM_LB_GRAD
-#define TM_LB_GRAD 2   // same for the gradient kernel
+#define TM_LB_GRAD 3   // same for the gradient kernel (168 VGPRs, a 20-byte spill on the rare l=3 path)
 #endif
 template <int KU, bool GRAD>
 __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     __shared__ double s_lxc;
     __shared__ double s_t0[TM_MAXH];
     __shared__ double s_noise[TM_NOISE_DOUBLES];
-    __shared__ double s_red[TM_WAVES][TM_GSLOTS];
+    __shared__ double s_red[2][TM_WAVES][TM_GSLOTS];   // double-buffered: one barrier per multiplet in pass 2
 
     const TmMult *gm = a.mult + (size_t)chain * a.n_mult;
     const TmNoise *gn = a.noise + chain;
@@ -430,12 +430,12 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     }
     S1 = tm_wave_sum(S1);
     S2 = tm_wave_sum(S2);
-    if (lane == 0) { s_red[wave][0] = S1; s_red[wave][1] = S2; }
+    if (lane == 0) { s_red[0][wave][0] = S1; s_red[0][wave][1] = S2; }
     __syncthreads();
     if (tid == 0) {
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[wv][0]; t2 += s_red[wv][1]; }
+        for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
         double *out = a.part + ((size_t)chain * a.tiles + tile) * 2;
         out[0] = t1;
         out[1] = t2;
@@ -443,24 +443,25 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
 
     // ---------------- pass 2: gradient partial sums ----------------
     if (GRAD) {
+        __syncthreads();   // s_red[0] (likelihood) consumed; s_w complete
         for (int jj = 0; jj < nact; jj++) {
             const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + s_idx[jj];
             const int nc = sm->ncomp;
-            __syncthreads();   // s_red free (also orders s_w writes before the first read)
+            double *red = s_red[(jj + 1) & 1][wave];
             if (sm->has_asym) {
                 switch (nc) {
-                case 1: tm_grad_mult<1, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-                case 3: tm_grad_mult<3, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-                case 5: tm_grad_mult<5, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-                default: tm_grad_mult<7, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                case 1: tm_grad_mult<1, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                case 3: tm_grad_mult<3, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                case 5: tm_grad_mult<5, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                default: tm_grad_mult<7, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
                 }
             } else {
-                if (lane == 0) { s_red[wave][21] = 0.0; s_red[wave][22] = 0.0; s_red[wave][23] = 0.0; }
+                if (lane == 0) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
                 switch (nc) {
-                case 1: tm_grad_mult<1, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-                case 3: tm_grad_mult<3, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-                case 5: tm_grad_mult<5, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
-                default: tm_grad_mult<7, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, s_red[wave]); break;
+                case 1: tm_grad_mult<1, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                case 3: tm_grad_mult<3, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                case 5: tm_grad_mult<5, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                default: tm_grad_mult<7, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
                 }
             }
             __syncthreads();
@@ -468,16 +469,15 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 double t = 0.0;
                 if (tid < 3 * nc || tid >= 21) {
 #pragma unroll
-                    for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[wv][tid];
+                    for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[(jj + 1) & 1][wv][tid];
                 }
                 a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + s_idx[jj]) * TM_GSLOTS + tid] = t;
             }
         }
         // noise terms: per Harvey k: sum w u, sum w t u^2, sum w t u^2 (lt + lx); then sum w  (u = 1/(1+t))
-        double gn_[TM_NSLOTS];
+        double gn_[TM_GSLOTS];
 #pragma unroll
-        for (int s = 0; s < TM_NSLOTS; s++) gn_[s] = 0.0;
-        __syncthreads();
+        for (int s = 0; s < TM_GSLOTS; s++) gn_[s] = 0.0;
 #pragma unroll 1
         for (int u = 0; u < S; u++) {
 #pragma unroll
@@ -514,16 +514,19 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 }
             }
         }
-#pragma unroll
-        for (int s = 0; s < TM_NSLOTS; s++) {
-            const double v = tm_wave_sum(gn_[s]);
-            if (lane == 0) s_red[wave][s] = v;
+        {
+            static_assert(TM_NSLOTS == 16, "butterfly below assumes 16 noise slots");
+            TmBfly<TM_NSLOTS, 32>::run(gn_, lane);
+            bool valid = true;
+            const int slot = TmBfly<TM_NSLOTS, 32>::slot_of(lane, valid);
+            double *red = s_red[(nact + 1) & 1][wave];   // the buffer the last multiplet did not use
+            if ((lane & 3) == 0) red[slot] = gn_[0];
         }
         __syncthreads();
         if (tid < TM_NSLOTS) {
             double t = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[wv][tid];
+            for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[(nact + 1) & 1][wv][tid];
             a.gnoise[((size_t)chain * a.tiles + tile) * TM_NSLOTS + tid] = t;
         }
     }

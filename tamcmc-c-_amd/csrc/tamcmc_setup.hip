@@ -10,7 +10,8 @@
 #include "tamcmc_derive.h"
 
 __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
-                                                          TmMult *__restrict__ mult, TmNoise *__restrict__ noise)
+                                                          TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
+                                                          TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux)
 {
     const int chain = blockIdx.x;
     const int tid = threadIdx.x;
@@ -18,18 +19,24 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
     double *p = s_p;
     for (int e = tid; e < L.Nparams; e += 64) p[e] = params[(size_t)chain * L.Nparams + e];
     __shared__ TmChain C;
+    __shared__ TmMultFull s_M[64];    // per-lane scratchpad: dynamically indexed fields stay out of scratch memory
     __shared__ int s_status;
     __syncthreads();
 
-    if (tid == 0) {
-        s_status = 0;
-        if (L.family != TM_FAM_GAUSS) tm_derive_chain(L, p, C);
+    if (tid == 0) s_status = 0;
+    if (L.family != TM_FAM_GAUSS) {
+        tm_derive_chain_coop(L, p, C, tid);
+        // keep the chain record for the backward kernel (gradient path)
+        if (chain_rec != nullptr)
+            for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += 64)
+                reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
+    } else {
+        __syncthreads();
     }
-    __syncthreads();
 
     if (L.family != TM_FAM_GAUSS) {
         for (int j = tid; j < L.n_mult; j += 64) {
-            TmMultFull M;
+            TmMultFull &M = s_M[tid];
             tm_derive_mult(L, C, p, j, M);
             TmMult out;
             const double g2 = M.W * M.W;
@@ -48,12 +55,14 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
             out.imin = M.imin; out.imax = M.imax; out.ncomp = M.ncomp;
             if (M.status != 0) atomicMax(&s_status, M.status);
             mult[(size_t)chain * L.n_mult + j] = out;
+            if (aux != nullptr) aux[(size_t)chain * L.n_mult + j] = M;
         }
     }
     __syncthreads();
 
+    __shared__ TmNoise s_N;           // N.H[N.nh] is dynamically indexed: LDS, not scratch
     if (tid == 0) {
-        TmNoise N;
+        TmNoise &N = s_N;
         for (int k = 0; k < TM_MAXH; k++) { N.H[k] = 0.0; N.lt[k] = 0.0; N.p[k] = 0.0; }
         N.N0 = 0.0; N.gA = 0.0; N.gnu0 = 0.0; N.gs2 = 1.0; N.nh = 0; N.has_gauss = 0; N.pad = 0;
         int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
@@ -82,9 +91,13 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
     }
 }
 
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise, void *stream)
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise,
+                    void *d_chain_rec, void *d_aux, void *stream)
 {
     hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(64), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
-                       d_params, d_mult, d_noise);
+                       d_params, d_mult, d_noise, static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux));
     return (int)hipGetLastError();
 }
+
+size_t tm_sizeof_chain_rec() { return sizeof(TmChain); }
+size_t tm_sizeof_aux() { return sizeof(TmMultFull); }
