@@ -106,6 +106,9 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         }
     }
     __syncthreads();
+#if defined(TM_BW_STOP) && TM_BW_STOP == 1
+    return;   // timing-only build
+#endif
 
     // ---------------- phase 1: per multiplet ----------------
     // phase 1a: every (multiplet, slot) pair sums its tile partials in tile order -- all threads, LDS result
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         s_G[item] = acc;
     }
     __syncthreads();
+#if defined(TM_BW_STOP) && TM_BW_STOP == 2
+    return;   // timing-only build
+#endif
     // phase 1b: chain rule, one thread per multiplet (records read in place: no private arrays -> no scratch)
     for (int j = tid; j < nm; j += TM_BW_THREADS) {
         const TmMultFull &M = auxp[j];
@@ -247,6 +253,9 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         pi[np] = M.idx_f; pv[np] = adj_f; np++;
     }
     __syncthreads();
+#if defined(TM_BW_STOP) && TM_BW_STOP == 3
+    return;   // timing-only build
+#endif
 
     // ---------------- phase 2: chain-level adjoints and noise ----------------
     if (tid < TM_NSHARED) {
@@ -255,6 +264,9 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         s_S[tid] = acc;
     }
     __syncthreads();
+#if defined(TM_BW_STOP) && TM_BW_STOP == 4
+    return;   // timing-only build
+#endif
     if (tid == 0) {
         int *pi = pair_idx + nm * TM_NPAIR;
         double *pv = pair_val + nm * TM_NPAIR;
@@ -308,6 +320,11 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             if (L.family == TM_FAM_GLOBAL && id != 13)
                 for (int l = 1; l <= L.lmax; l++) { pi[np] = L.Nmax + l - 1; pv[np] = tm_sign(p[L.Nmax + l - 1]) * adj_V[l]; np++; }
         }
+    }
+    if (tid == 64) {   // noise terms on another wave, concurrently with the chain-level work of thread 0
+        int *pi = pair_idx + nm * TM_NPAIR + (ncp - 16);
+        double *pv = pair_val + nm * TM_NPAIR + (ncp - 16);
+        int np = 0;
         // noise terms: sum the per-tile partials in tile order
         const double *Gn = s_gn;
         int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
@@ -339,13 +356,27 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         }
     }
     __syncthreads();
+#if defined(TM_BW_STOP) && TM_BW_STOP == 5
+    return;   // timing-only build
+#endif
 
     // ---------------- phase 3: gather per variable, in pair order ----------------
     for (int k = tid; k < Nvars; k += TM_BW_THREADS) {
         const int target = relax[k];
         double acc = 0.0;
-        for (int e = 0; e < npairs_max; e++)
-            if (pair_idx[e] == target) acc += pair_val[e];
+        // pair order is preserved; eight loads in flight per step (a plain loop is one LDS latency per pair)
+        for (int e0 = 0; e0 < npairs_max; e0 += 8) {
+            int id[8];
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int e = (e0 + q < npairs_max) ? e0 + q : npairs_max - 1;
+                id[q] = (e0 + q < npairs_max) ? pair_idx[e] : -1;
+                v[q] = pair_val[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc += (id[q] == target) ? v[q] : 0.0;
+        }
         grad[(size_t)chain * Nvars + k] = acc;
     }
 }

@@ -12,7 +12,7 @@
 #include <stdint.h>
 
 #define TM_MAXM 7      // components of a multiplet: 2l+1, l <= 3 (build_lorentzian.cpp:74)
-#define TM_MAXH 4      // Harvey profiles per chain (Nnoise = 3*Nharvey+1, models.cpp:624)
+#define TM_MAXH 3      // Harvey profiles per chain (Nnoise = 3*Nharvey+1 = 10 in every .model file, io_ms_global.cpp)
 #define TM_THREADS 256 // threads per workgroup of the eval kernel (4 waves of 64)
 #define TM_MAXMULT 256 // multiplets per chain (Nmax*(lmax+1) or sum Nfl); staged in LDS, 160 B each
 #define TM_GSLOTS 24   // gradient partials per (tile, multiplet): 3 per component + 3 asymmetry sums
@@ -66,8 +66,8 @@ struct TmNoise {
     int32_t pad;
 };
 
-static_assert(sizeof(TmNoise) == 144, "TmNoise layout");
-#define TM_NOISE_DOUBLES 18
+static_assert(sizeof(TmNoise) == 120, "TmNoise layout");
+#define TM_NOISE_DOUBLES 15
 
 struct TmEvalArgs {
     const double *x, *y, *lx, *isig2;

@@ -210,6 +210,10 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__r
             }
         }
     }
+#if defined(TM_ABLATE) && (TM_ABLATE & 1)   // timing-only build: no wave reduction of the partials
+    if (lane == 0) s_red_row[0] = g[0] + g[1] + g[2];
+    return;
+#endif
     TmBfly<V, 32>::run(g, lane);
     // lanes whose plainly-reduced low bits are zero publish; padded slots are skipped
     constexpr int NSPLIT = (V > 16) ? 5 : (V > 8) ? 4 : (V > 4) ? 3 : (V > 2) ? 2 : 1;   // butterfly levels that split
@@ -226,13 +230,15 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__r
 #define TM_LB_FWD 4    // resident waves per SIMD the register allocator must allow (likelihood-only kernel)
 #endif
 #ifndef TM_LB_GRAD
-#define TM_LB_GRAD 3   // same for the gradient kernel (168 VGPRs, a 20-byte spill on the rare l=3 path)
+#define TM_LB_GRAD 2   // same for the gradient kernel (no spills; 3 was measured slower: it spills)
 #endif
 template <int KU, bool GRAD>
 __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
 {
     const int S = a.S;
     const int TB = TM_THREADS * KU * S;
+    constexpr int KU2 = (KU > 2) ? 2 : KU;   // pass 2 keeps 3 accumulators per component: fewer bins in flight
+    const int Sp2 = S * (KU / KU2);          // sub-blocks of pass 2
     const int tile = blockIdx.x, chain = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int base = tile * TB;
@@ -307,11 +313,14 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     double P = 1.0;
     int esum = 0;
     bool bad = false;
+    double gn_[GRAD ? TM_GSLOTS : 1];   // GRAD: noise partial sums (3 per Harvey, sum w at slot 3*TM_MAXH, Gaussian at 13..15)
+#pragma unroll
+    for (int s_ = 0; s_ < (GRAD ? TM_GSLOTS : 1); s_++) gn_[s_] = 0.0;
     const double wscale = GRAD ? ((a.likelihood_case == 0) ? a.like_p / a.Tcoefs[chain] : 2.0 / a.Tcoefs[chain]) : 0.0;
 
 #pragma unroll 1
     for (int u = 0; u < S; u++) {
-        double x2[KU], acc[KU];
+        double x2[KU], acc[KU], wreg[GRAD ? KU : 1];
         int bi[KU];
 #pragma unroll
         for (int k = 0; k < KU; k++) {
@@ -341,28 +350,49 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 }
             }
         }
+        double hu[TM_MAXH][GRAD ? KU : 1], harg[GRAD ? KU : 1];   // GRAD: u = 1/(1+t) per Harvey and bin (t u = 1 - u), log x per bin
         if (nh > 0) {
             double dl[KU];
 #pragma unroll
-            for (int k = 0; k < KU; k++) dl[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1];
+            for (int k = 0; k < KU; k++) { dl[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1]; if constexpr (GRAD) harg[k] = dl[k]; }
             if (npoly) {
 #pragma unroll
                 for (int k = 0; k < KU; k++) dl[k] -= lxc;
-                for (int h = 0; h < nh; h++) {
-                    const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
+                if constexpr (GRAD) {
 #pragma unroll
-                    for (int k = 0; k < KU; k++) {
-                        const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
-                        acc[k] = __builtin_fma(Hh, tm_rcp(t + 1.0), acc[k]);
+                    for (int h = 0; h < TM_MAXH; h++) {
+                        if (h < nh) {
+                            const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
+#pragma unroll
+                            for (int k = 0; k < KU; k++) {
+                                const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
+                                hu[h][k] = tm_rcp(t + 1.0);
+                                acc[k] = __builtin_fma(Hh, hu[h][k], acc[k]);
+                            }
+                        }
+                    }
+                } else {
+                    for (int h = 0; h < nh; h++) {
+                        const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
+#pragma unroll
+                        for (int k = 0; k < KU; k++) {
+                            const double t = t0 * tm_exp_small(ph * dl[k]);
+                            acc[k] = __builtin_fma(Hh, tm_rcp(t + 1.0), acc[k]);
+                        }
                     }
                 }
             } else {
-                for (int h = 0; h < nh; h++) {
-                    const double Hh = sn->H[h], ph = sn->p[h], lth = sn->lt[h];
 #pragma unroll
-                    for (int k = 0; k < KU; k++) {
-                        const double t = exp(ph * (lth + dl[k]));
-                        acc[k] += Hh * (1.0 / (t + 1.0));
+                for (int h = 0; h < TM_MAXH; h++) {
+                    if (h < nh) {
+                        const double Hh = sn->H[h], ph = sn->p[h], lth = sn->lt[h];
+#pragma unroll
+                        for (int k = 0; k < KU; k++) {
+                            const double t = exp(ph * (lth + dl[k]));
+                            const double uu = 1.0 / (t + 1.0);
+                            acc[k] += Hh * uu;
+                            if constexpr (GRAD) hu[h][k] = uu;
+                        }
                     }
                 }
             }
@@ -401,7 +431,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                     esum += e;
                     wv = wscale * (yv * rM * rM - rM);   // d(logL/T)/dM_i
                 }
-                if (GRAD) s_w[(u * KU + k) * TM_THREADS + tid] = wv;
+                if constexpr (GRAD) { s_w[(u * KU + k) * TM_THREADS + tid] = wv; wreg[k] = wv; }
             }
             {
                 int e;
@@ -419,7 +449,35 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                     S1 = __builtin_fma(dd * dd, is2, S1);
                     wv = wscale * dd * is2;
                 }
-                if (GRAD) s_w[(u * KU + k) * TM_THREADS + tid] = wv;
+                if constexpr (GRAD) { s_w[(u * KU + k) * TM_THREADS + tid] = wv; wreg[k] = wv; }
+            }
+        }
+        if constexpr (GRAD) {
+            // noise partial sums, reusing u and t*u of this sub-block (no second pass over the bins)
+#pragma unroll
+            for (int k = 0; k < KU; k++) {
+                const double wk = wreg[k];
+                gn_[3 * TM_MAXH] += wk;
+                if (nh > 0) {
+#pragma unroll
+                    for (int h = 0; h < TM_MAXH; h++) {
+                        if (h < nh) {
+                            const double wu = wk * hu[h][k];
+                            const double tu2 = wu * (1.0 - hu[h][k]);   // t u = 1 - u
+                            gn_[3 * h] += wu;
+                            gn_[3 * h + 1] += tu2;
+                            gn_[3 * h + 2] = __builtin_fma(tu2, sn->lt[h] + harg[k], gn_[3 * h + 2]);
+                        }
+                    }
+                }
+                if (has_gauss) {
+                    // Gaussian term: sum w e, sum w e d, sum w e d^2 with e = exp(-0.5 d^2/s2), d = x - nu0
+                    const double dd = 0.5 * x2[k] - sn->gnu0;
+                    const double we = wk * exp((-0.5 * (dd * dd)) / sn->gs2);
+                    gn_[13] += we;
+                    gn_[14] = __builtin_fma(we, dd, gn_[14]);
+                    gn_[15] = __builtin_fma(we * dd, dd, gn_[15]);
+                }
             }
         }
     }
@@ -442,26 +500,30 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     }
 
     // ---------------- pass 2: gradient partial sums ----------------
-    if (GRAD) {
+    if constexpr (GRAD) {
         __syncthreads();   // s_red[0] (likelihood) consumed; s_w complete
+#if defined(TM_ABLATE) && (TM_ABLATE & 2)   // timing-only build: no multiplet pass 2 at all
+        for (int jj = 0; jj < 0; jj++) {
+#else
         for (int jj = 0; jj < nact; jj++) {
+#endif
             const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + s_idx[jj];
             const int nc = sm->ncomp;
             double *red = s_red[(jj + 1) & 1][wave];
             if (sm->has_asym) {
                 switch (nc) {
-                case 1: tm_grad_mult<1, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
-                case 3: tm_grad_mult<3, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
-                case 5: tm_grad_mult<5, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
-                default: tm_grad_mult<7, KU, true>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                case 1: tm_grad_mult<1, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
+                case 3: tm_grad_mult<3, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
+                case 5: tm_grad_mult<5, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
+                default: tm_grad_mult<7, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
                 }
             } else {
                 if (lane == 0) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
                 switch (nc) {
-                case 1: tm_grad_mult<1, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
-                case 3: tm_grad_mult<3, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
-                case 5: tm_grad_mult<5, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
-                default: tm_grad_mult<7, KU, false>(sm, a.x, s_w, base, S, a.Nx, tid, lane, red); break;
+                case 1: tm_grad_mult<1, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
+                case 3: tm_grad_mult<3, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
+                case 5: tm_grad_mult<5, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
+                default: tm_grad_mult<7, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
                 }
             }
             __syncthreads();
@@ -474,46 +536,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + s_idx[jj]) * TM_GSLOTS + tid] = t;
             }
         }
-        // noise terms: per Harvey k: sum w u, sum w t u^2, sum w t u^2 (lt + lx); then sum w  (u = 1/(1+t))
-        double gn_[TM_GSLOTS];
-#pragma unroll
-        for (int s = 0; s < TM_GSLOTS; s++) gn_[s] = 0.0;
-#pragma unroll 1
-        for (int u = 0; u < S; u++) {
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                const int i = base + (u * KU + k) * TM_THREADS + tid;
-                const int ii = i < a.Nx ? i : a.Nx - 1;
-                const double wk = s_w[(u * KU + k) * TM_THREADS + tid];   // 0 for bins beyond Nx
-                gn_[3 * TM_MAXH] += wk;
-                if (nh > 0) {
-                    const double lxk = a.lx[ii];
-#pragma unroll
-                    for (int h = 0; h < TM_MAXH; h++) {
-                        if (h < nh) {
-                            const double ph = sn->p[h];
-                            const double arg = sn->lt[h] + lxk;
-                            double t = npoly ? s_t0[h] * tm_exp_small(ph * (lxk - lxc)) : exp(ph * arg);
-                            t = (t > 1e300) ? 1e300 : t;
-                            const double uu = tm_rcp(t + 1.0);
-                            const double wu = wk * uu;
-                            const double tu2 = wu * (t * uu);
-                            gn_[3 * h] += wu;
-                            gn_[3 * h + 1] += tu2;
-                            gn_[3 * h + 2] = __builtin_fma(tu2, arg, gn_[3 * h + 2]);
-                        }
-                    }
-                }
-                if (has_gauss) {
-                    // Gaussian term: sum w e, sum w e d, sum w e d^2 with e = exp(-0.5 d^2/s2), d = x - nu0
-                    const double dd = a.x[ii] - sn->gnu0;
-                    const double we = wk * exp((-0.5 * (dd * dd)) / sn->gs2);
-                    gn_[13] += we;
-                    gn_[14] = __builtin_fma(we, dd, gn_[14]);
-                    gn_[15] = __builtin_fma(we * dd, dd, gn_[15]);
-                }
-            }
-        }
+        // noise partial sums were accumulated in pass 1 (gn_): reduce and publish them
         {
             static_assert(TM_NSLOTS == 16, "butterfly below assumes 16 noise slots");
             TmBfly<TM_NSLOTS, 32>::run(gn_, lane);

@@ -22,6 +22,9 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
     __shared__ TmMultFull s_M[64];    // per-lane scratchpad: dynamically indexed fields stay out of scratch memory
     __shared__ int s_status;
     __syncthreads();
+#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 1
+    return;   // timing-only build
+#endif
 
     if (tid == 0) s_status = 0;
     if (L.family != TM_FAM_GAUSS) {
@@ -59,6 +62,9 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
         }
     }
     __syncthreads();
+#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
+    return;   // timing-only build
+#endif
 
     __shared__ TmNoise s_N;           // N.H[N.nh] is dynamically indexed: LDS, not scratch
     if (tid == 0) {
