@@ -1,0 +1,119 @@
+/*
+ * tamcmc_sampler.h -- host-side callers of the hot path, in C++
+ * behind a C ABI like the rest of the library:
+ *
+ *   N1  log-priors            priors_calc.cpp:24-417, stats_dictionary.cpp:31-241,
+ *                             derivatives_handler.cpp:342-455
+ *   N2  batched sampler       MALA.cpp:53-112 (setup), :246-289 (init_proposal), :292-315 (update_proposal),
+ *                             :335-353 (new_prop_values), :381-445 (parallel_tempering), :447-538
+ *                             (update_position_MH), :608-692 (execute loop); random_JB.cpp:22-259 (RNG)
+ *
+ * The reference's "MALA" is an adaptive random-walk Metropolis with parallel tempering (no gradient,
+ * MALA.cpp:18); this restates exactly that, with three deliberate differences, none of which changes a
+ * result: (1) every chain's proposal is drawn first (same RNG order: u then z per chain, chain 0..N-1),
+ * then ALL chains are evaluated in ONE evaluator call, then accepted -- legal because draws do not
+ * depend on outcomes; (2) the seed is an argument instead of time(NULL), and the
+ * generator is a private copy of glibc's rand() algorithm (TYPE_3 additive feedback), so runs are
+ * reproducible and independent of other users of rand(); (3) the Cholesky factor is cached while the
+ * proposal is not being adapted.  MaxChain = 24 (MALA.cpp:565-572) is not enforced.
+ *
+ * Sharded runs (one process per GPU): every rank creates the sampler with the GLOBAL chain count and its
+ * own [chain_offset, chain_offset + n_local) block; every rank consumes the whole random stream, so the
+ * chains are bit-identical to a single-process run.  A parallel-tempering pair that straddles two ranks
+ * is exchanged by the caller (torch.distributed send/recv) through tamcmc_sampler_pt_* below.
+ */
+#ifndef TAMCMC_SAMPLER_H
+#define TAMCMC_SAMPLER_H
+
+#include <stdint.h>
+#include "tamcmc_accel.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tamcmc_sampler tamcmc_sampler;
+
+/* Evaluator: tempered log-likelihood of n chains (the hot path).  Returns 0 or an error code.
+ * tamcmc_eval_batch has this shape once its ctx is bound (tamcmc_sampler_create_hip does that). */
+typedef int (*tamcmc_eval_fn)(void *user, int32_t nchains, int32_t nparams, const double *params,
+                              const double *Tcoefs, double *logL, int32_t *status);
+
+#define TAMCMC_MAX_LEARN 8
+
+typedef struct {
+    int32_t Nchains;            /* global number of tempered chains                         MALA_cfg::Nchains     */
+    int32_t chain_offset;       /* first chain owned by this process (0 for a single process)                      */
+    int32_t Nchains_local;      /* chains owned by this process (= Nchains for a single process)                   */
+    double  lambda_temp;        /* Tcoefs[m] = lambda_temp^m                                 MALA.cpp:103          */
+    double  target_acceptance;  /* 0.234                                                     config_default.cfg:9  */
+    double  c0, epsilon1, epsilon2, A1;  /* Robbins-Monro constants                          config_default.cfg:10-13 */
+    int64_t dN_mixing;          /* PT attempt every dN_mixing iterations (i != 0)            MALA.cpp:676          */
+    int32_t n_learn;            /* entries of Nt_learn (periods_learn has n_learn-1)         MALA.cpp:641-652      */
+    int64_t Nt_learn[TAMCMC_MAX_LEARN];
+    int64_t periods_learn[TAMCMC_MAX_LEARN];
+    uint32_t seed;              /* srand(seed)                                               MALA.cpp:62-63        */
+    int32_t prior_fct_switch;   /* priors_ctrl.list: 0 Test_Gaussian, 1 Harvey_Gaussian, 2 io_MS_Global, 3 io_local */
+} tamcmc_sampler_cfg;
+
+/* priors_params: n_prior_rows x Nparams, row-major (Input_Data::priors, one column per parameter);
+ * priors_names_switch: Nparams primitive-prior ids (primepriors_ctrl.list); extra_priors: 4 values
+ * (smooth switch, smoothness coefficient, a3/a1 limit, impose_normHnlm; priors_calc.cpp:28-31).
+ * err: Nvars initial proposal errors (init_proposal's error[i] = var*frac + offset, MALA.cpp:249-257). */
+int tamcmc_sampler_create(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg,
+                          tamcmc_eval_fn eval, void *eval_user,
+                          int32_t Nparams, const int32_t plength[11], const double *inputs, const int32_t *relax,
+                          const int32_t *priors_names_switch, const double *priors_params, int32_t n_prior_rows,
+                          const double extra_priors[4], const double *err);
+
+/* Convenience: the evaluator is a HIP context (tamcmc_eval_batch on it). */
+int tamcmc_sampler_create_hip(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, tamcmc_ctx *ctx,
+                              int32_t Nparams, const int32_t plength[11], const double *inputs, const int32_t *relax,
+                              const int32_t *priors_names_switch, const double *priors_params, int32_t n_prior_rows,
+                              const double extra_priors[4], const double *err);
+
+/* Model_def constructor's initial generate_model() of every chain (model_def.cpp:139-143). */
+int tamcmc_sampler_init(tamcmc_sampler *s);
+
+/* One iteration of MALA::execute's loop body WITHOUT the parallel-tempering step (MALA.cpp:630-655). */
+int tamcmc_sampler_mh_step(tamcmc_sampler *s);
+
+/* Parallel tempering, split so that a boundary pair can be exchanged by the caller:
+ *   pt_due    1 if this iteration attempts a swap (i % dN_mixing == 0 && i != 0)
+ *   pt_draw   consumes u and A from the random stream (every rank calls it: same values everywhere)
+ *   pt_local  performs the attempt when both chains are owned here; returns swapped 0/1 in *swapped
+ *   pt_export copies {logL, logPrior, moved, Pmove, params[Nparams], vars[Nvars]} of an owned chain
+ *   pt_import finishes a boundary attempt on this rank given the peer's exported record
+ *   end_iteration advances the iteration counter (call once per iteration, after the PT step if any) */
+int tamcmc_sampler_pt_due(const tamcmc_sampler *s);
+int tamcmc_sampler_pt_draw(tamcmc_sampler *s, int32_t *A, double *u);
+int tamcmc_sampler_pt_local(tamcmc_sampler *s, int32_t A, double u, int32_t *swapped, double *r_T);
+int tamcmc_sampler_pt_record_size(const tamcmc_sampler *s);
+int tamcmc_sampler_pt_export(const tamcmc_sampler *s, int32_t chain, double *record);
+int tamcmc_sampler_pt_import(tamcmc_sampler *s, int32_t A, double u, const double *peer_record, int32_t *swapped, double *r_T);
+int tamcmc_sampler_end_iteration(tamcmc_sampler *s);
+
+/* Single process: n full iterations (mh_step + PT when due + end_iteration).
+ * moved_hist (may be NULL): n x Nchains_local acceptance flags; swap_hist (may be NULL): n entries,
+ * -1 no attempt, else 2*A + swapped. */
+int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, int32_t *swap_hist);
+
+/* State access (local chains, row-major). which: 0 vars, 1 params, 2 logLikelihood (tempered), 3 logPrior,
+ * 4 logPosterior, 5 Pmove, 6 sigma, 7 mu, 8 covarmat (n_local x Nvars x Nvars), 9 Tcoefs (local) */
+int tamcmc_sampler_get(const tamcmc_sampler *s, int32_t which, double *out, int64_t capacity);
+int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s);
+int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s);
+int tamcmc_sampler_destroy(tamcmc_sampler *s);
+
+/* N1 entry points, exported for tests (known answers of stats_dictionary.cpp:252-326). */
+double tamcmc_logP_primitive(int32_t prior_id, const double p[4], double x);
+double tamcmc_log_prior(int32_t prior_fct_switch, int32_t Nparams, const double *params, const int32_t plength[11],
+                        const int32_t *priors_names_switch, const double *priors_params, int32_t n_prior_rows,
+                        const double extra_priors[4], int32_t *error);
+/* the private copy of glibc's rand(): fills out[n] after srand(seed) (test hook) */
+void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -10,7 +10,7 @@ Contents (only what the hot path needs):
   model_def.py     host-side mirror of the reference's Model_def plugin surface (model_def.h:23-83)
   synth.py         synthetic spectra / chain parameters of SURVEY.md section 8d
 """
-from . import capi, synth, model_def, shard  # noqa: F401
+from . import capi, synth, model_def, shard, sampler  # noqa: F401
 from .capi import Accel, AccelError, load_library, library_path  # noqa: F401
 from .model_def import ModelDef, Data  # noqa: F401
 

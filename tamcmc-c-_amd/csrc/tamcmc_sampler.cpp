@@ -1,0 +1,692 @@
+// tamcmc_sampler.cpp -- host-side callers of the hot path: log-priors (N1) and the batched adaptive
+// Metropolis + parallel-tempering sampler (N2).  See include/tamcmc_sampler.h for the map to the
+// reference.  Plain C++17, no Eigen: matrices are row-major std::vector<double>.
+#include "tamcmc_sampler.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+namespace {
+
+typedef long double ld;
+const ld PIl = 3.141592653589793238462643383279502884L;   // stats_dictionary.cpp:23
+const ld NEG_INF = -std::numeric_limits<ld>::infinity();
+
+// ------------------------------------------------------------------------------------------------
+// N1: primitive priors, stats_dictionary.cpp:31-241 (long double like the reference)
+// ------------------------------------------------------------------------------------------------
+ld logP_uniform(ld b_min, ld b_max, ld x) { return ((x <= b_max) && (x >= b_min)) ? -std::log(std::fabs(b_max - b_min)) : NEG_INF; }
+ld logP_uniform_abs(ld b_min, ld b_max, ld x) { return ((std::fabs(x) <= b_max) && (std::fabs(x) >= b_min)) ? -std::log(std::fabs(b_max - b_min)) : NEG_INF; }
+ld logP_uniform_cos(ld b_min, ld b_max, ld x)
+{
+    const ld x_rad = PIl * x / 180.;
+    return ((std::cos(x_rad) < b_max) && (std::cos(x_rad) > b_min)) ? -std::log(std::fabs(b_max - b_min)) : NEG_INF;
+}
+ld logP_gaussian(ld mean, ld sigma, ld x) { return -std::log(std::sqrt(2 * PIl) * sigma) - 0.5 * std::pow((x - mean) / sigma, (ld)2.); }
+ld logP_jeffrey(ld hmin, ld hmax, ld h)
+{
+    if (h < hmax && h > 0) {
+        const ld prior = 1. / (h + hmin), norm = std::log((hmax + hmin) / hmin);
+        return std::log(prior / norm);
+    }
+    return NEG_INF;
+}
+ld logP_jeffrey_abs(ld hmin, ld hmax, ld h)
+{
+    if (std::fabs(h) < hmax) {
+        const ld prior = 1. / (std::fabs(h) + hmin), norm = std::log((hmax + hmin) / hmin);
+        return std::log(prior / norm);
+    }
+    return NEG_INF;
+}
+ld logP_uniform_gaussian(ld b_min, ld b_max, ld sigma, ld x)
+{
+    ld logP = std::numeric_limits<ld>::quiet_NaN();   // uninitialised in the reference when x is NaN
+    if (x < b_min) logP = NEG_INF;
+    if ((x <= b_max) && (x >= b_min)) logP = 0;
+    if (x > b_max) logP = -0.5 * std::pow((x - b_max) / sigma, (ld)2.);
+    const ld C = std::log(std::fabs(b_max - b_min) + 0.5 * std::sqrt(2 * PIl) * sigma);
+    return logP - C;
+}
+ld logP_gaussian_uniform(ld b_min, ld b_max, ld sigma, ld x)
+{
+    ld logP = std::numeric_limits<ld>::quiet_NaN();
+    if (x > b_max) logP = NEG_INF;
+    if ((x <= b_max) && (x >= b_min)) logP = 0;
+    if (x < b_min) logP = -0.5 * std::pow((x - b_min) / sigma, (ld)2.);
+    const ld C = std::log(std::fabs(b_max - b_min) + 0.5 * std::sqrt(2 * PIl) * sigma);
+    return logP - C;
+}
+ld logP_gaussian_uniform_gaussian(ld b_min, ld b_max, ld sigma1, ld sigma2, ld x)
+{
+    ld logP = std::numeric_limits<ld>::quiet_NaN();
+    if (x < b_min) logP = -0.5 * std::pow((x - b_min) / sigma1, (ld)2.);
+    if ((x <= b_max) && (x >= b_min)) logP = 0;
+    if (x > b_max) logP = -0.5 * std::pow((x - b_max) / sigma2, (ld)2.);
+    const ld C = std::log(std::fabs(b_max - b_min) + 0.5 * std::sqrt(2 * PIl) * (sigma1 + sigma2));
+    return logP - C;
+}
+
+// One primitive by its primepriors_ctrl.list id; p = column of Input_Data::priors.  *err set for ids the
+// reference exits on (3 multivariate Gaussian, unknown ids), priors_calc.cpp:315-417.
+ld primitive(int id, const double *p, int nrows, ld x, int *err)
+{
+    const ld p0 = nrows > 0 ? p[0] : 0, p1 = nrows > 1 ? p[1] : 0, p2 = nrows > 2 ? p[2] : 0, p3 = nrows > 3 ? p[3] : 0;
+    switch (id) {
+    case 0: return 0;
+    case 1: return logP_uniform(p0, p1, x);
+    case 2: return logP_gaussian(p0, p1, x);
+    case 3: if (err) *err = 1; return 0;
+    case 4: return logP_jeffrey(p0, p1, x);
+    case 5: return logP_uniform_gaussian(p0, p1, p2, x);
+    case 6: return logP_gaussian_uniform(p0, p1, p2, x);
+    case 7: return logP_gaussian_uniform_gaussian(p0, p1, p2, p3, x);
+    case 8: return logP_uniform_abs(p0, p1, x);
+    case 9: return logP_uniform_cos(p0, p1, x);
+    case 10: return logP_jeffrey_abs(p0, p1, x);
+    case 11: return 0;
+    default: if (err) *err = 1; return 0;
+    }
+}
+
+struct PriorSpec {
+    int fct = 0;                       // priors_ctrl.list id
+    int Nparams = 0, nrows = 0;
+    int plength[11] = {0};
+    std::vector<int32_t> sw;           // priors_names_switch
+    std::vector<double> pp;            // priors_params, nrows x Nparams
+    double extra[4] = {0, 0, 0, 0};
+};
+
+// apply_generic_priors, priors_calc.cpp:315-417
+ld apply_generic_priors(const PriorSpec &S, const double *params, int *err)
+{
+    ld pena = 0;
+    double col[4];
+    for (int i = 0; i < S.Nparams; i++) {
+        for (int r = 0; r < 4; r++) col[r] = (r < S.nrows) ? S.pp[(size_t)r * S.Nparams + i] : 0.0;
+        pena = pena + primitive(S.sw[i], col, S.nrows, params[i], err);
+    }
+    return pena;
+}
+
+// Frstder_adaptive_reggrid(y).deriv.sum(), derivatives_handler.cpp:342-367 (n >= 3)
+ld first_derivative_sum(const double *y, int n)
+{
+    ld s = 0;
+    s += y[1] - y[0];                                   // forward, 1st order, on the first two points
+    for (int i = 0; i < n - 2; i++) s += (y[i + 2] - y[i]) / 2.;   // centred
+    s += y[n - 1] - y[n - 2];                           // backward on the last two points
+    return s;
+}
+
+// Scndder_adaptive_reggrid(y).deriv[i], derivatives_handler.cpp:398-423
+double second_derivative(const double *y, int n, int i)
+{
+    if (i == 0) return y[2] - 2. * y[1] + y[0];
+    if (i == n - 1) return y[n - 1] - 2. * y[n - 2] + y[n - 3];
+    return y[i + 1] - 2. * y[i] + y[i - 1];
+}
+
+// priors_MS_Global, priors_calc.cpp:24-172
+ld priors_MS_Global(const PriorSpec &S, const double *params, int *err)
+{
+    ld f = 0;
+    const int smooth_switch = (int)S.extra[0];
+    const double scoef = S.extra[1], a3ova1_limit = S.extra[2];
+    const int impose_normHnlm = (int)S.extra[3];
+    const int Nmax = S.plength[0], lmax = S.plength[1];
+    const int Nfl[4] = {S.plength[2], S.plength[3], S.plength[4], S.plength[5]};
+    const int Nsplit = S.plength[6], Nwidth = S.plength[7], Nnoise = S.plength[8];
+    const int Nf = Nfl[0] + Nfl[1] + Nfl[2] + Nfl[3];
+    const int s = Nmax + lmax + Nf, q = s + Nsplit + Nwidth + Nnoise, z = s + Nsplit + Nwidth;
+
+    f = f + apply_generic_priors(S, params, err);
+    for (int i = Nmax; i <= Nmax + lmax; i++)            // inclusive upper bound as in the reference (:52)
+        if (params[i] < 0) f = NEG_INF;
+    switch (impose_normHnlm) {
+    case 1:
+        f = f + logP_uniform(0, 1. + 1e-10, params[q] + 2 * params[q + 1]);
+        f = f + logP_uniform(0, 1 + 1e-10, params[q + 2] + 2 * params[q + 3] + 2 * params[q + 4]);
+        f = f + logP_uniform(0, 1 + 1e-10, params[q + 5] + 2 * params[q + 6] + 2 * params[q + 7] + 2 * params[q + 8]);
+        break;
+    case 2: if (err) *err = 1; break;                    // "YET TO BE IMPLEMENTED" + exit in the reference (:83-85)
+    }
+    if (Nfl[0] < 3) { if (err) *err = 1; return f; }     // the derivative helpers exit on short vectors
+    const double *fl0 = params + Nmax + lmax;
+    const double Dnu = (double)first_derivative_sum(fl0, Nfl[0]);   // SUM of the derivative array (:90)
+    if (Nfl[0] == Nfl[2]) {
+        for (int i = 0; i < Nfl[0]; i++) {
+            const double d02 = params[Nmax + lmax + i] - params[Nmax + lmax + Nfl[0] + Nfl[1] + i];
+            f = f + logP_gaussian_uniform(0, Dnu / 3., 0.015 * Dnu, d02);
+        }
+    }
+    if (smooth_switch == 1) {
+        int off = Nmax + lmax;
+        for (int l = 0; l < 4; l++) {
+            if (Nfl[l] != 0) {
+                if (Nfl[l] < 3) { if (err) *err = 1; return f; }
+                for (int i = 0; i < Nfl[l]; i++) f = f + logP_gaussian(0, scoef, second_derivative(params + off, Nfl[l], i));
+            }
+            off += Nfl[l];
+        }
+    }
+    if (std::fabs(params[s + 2] / params[s]) >= a3ova1_limit) f = NEG_INF;
+    if (params[s + 4] < 0) f = NEG_INF;
+    if (S.sw[z + 3] != 0)
+        if ((params[z + 3] < 0) || (params[z + 4] < 0) || (params[z + 5] < 0)) f = NEG_INF;
+    if (S.sw[z + 6] != 0)
+        if ((params[z + 6] < 0) || (params[z + 7] < 0) || (params[z + 8] < 0)) f = NEG_INF;
+    if ((S.sw[s + 9] != 0) && (params[z + 9] < 0)) f = NEG_INF;   // index quirk of the reference (:166) kept
+    return f;
+}
+
+// priors_local, priors_calc.cpp:175-280
+ld priors_local(const PriorSpec &S, const double *params, int *err)
+{
+    ld f = 0;
+    const double a3ova1_limit = S.extra[2];
+    const int Nmax = S.plength[0], Nvis = S.plength[1];
+    const int Nf = S.plength[2] + S.plength[3] + S.plength[4] + S.plength[5];
+    const int s = Nmax + Nvis + Nf, q = s + S.plength[6] + S.plength[7] + S.plength[8];
+    f = f + apply_generic_priors(S, params, err);
+    if (params[s] != 0) {
+        if (std::fabs(params[s + 2] / params[s]) >= a3ova1_limit) f = NEG_INF;
+    } else if ((params[s + 3] != 0) && (params[s + 4] != 0)) {
+        if (std::fabs(params[s + 2] / (std::pow(params[s + 3], 2) + std::pow(params[s + 4], 2))) >= a3ova1_limit) f = NEG_INF;
+    }
+    if ((S.sw[q] != 0) && (params[q] < 0)) f = NEG_INF;
+    return f;
+}
+
+ld log_prior(const PriorSpec &S, const double *params, int *err)
+{
+    switch (S.fct) {
+    case 0: case 1: return apply_generic_priors(S, params, err);   // priors_Test_Gaussian / _Harvey_Gaussian (:288-310)
+    case 2: return priors_MS_Global(S, params, err);
+    case 3: return priors_local(S, params, err);
+    default: if (err) *err = 1; return 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RNG: glibc rand()/srand() (TYPE_3, r[i] = r[i-3] + r[i-31]) + random_JB.cpp's Box-Muller
+// ------------------------------------------------------------------------------------------------
+struct GlibcRand {
+    int32_t r[31];
+    int f = 3, b = 0;
+    void seed(uint32_t s)
+    {
+        if (s == 0) s = 1;
+        r[0] = (int32_t)s;
+        for (int i = 1; i < 31; i++) {
+            const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+            long word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            r[i] = (int32_t)word;
+        }
+        f = 3; b = 0;
+        for (int i = 0; i < 310; i++) (void)next();
+    }
+    int32_t next()
+    {
+        const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)v;
+        const int32_t out = (int32_t)(v >> 1);
+        if (++f >= 31) f = 0;
+        if (++b >= 31) b = 0;
+        return out;
+    }
+};
+
+struct Rng {
+    GlibcRand g;
+    int saved = 0;       // random_JB.cpp: static int saved; static double y
+    double y = 0.0;
+    double uniform() { return (double)g.next() / 2147483647.0; }   // random_JB.cpp:255
+    // r8vec_normal_01(n), random_JB.cpp:22-213
+    void normals(int n, double *x)
+    {
+        const double PI = 3.141592653589793;
+        if (n <= 0) return;
+        int x_lo = 1, x_hi = n;
+        if (saved == 1) { x[0] = y; saved = 0; x_lo = 2; }
+        const int cnt = x_hi - x_lo + 1;
+        if (cnt == 0) {
+        } else if (cnt == 1) {
+            const double r0 = uniform(), r1 = uniform();
+            x[x_hi - 1] = std::sqrt(-2.0 * std::log(r0)) * std::cos(2.0 * PI * r1);
+            y = std::sqrt(-2.0 * std::log(r0)) * std::sin(2.0 * PI * r1);
+            saved = 1;
+        } else if (cnt % 2 == 0) {
+            const int m = cnt / 2;
+            std::vector<double> r(2 * m);
+            for (auto &v : r) v = uniform();
+            for (int i = 0; i <= 2 * m - 2; i += 2) {
+                x[x_lo + i - 1] = std::sqrt(-2.0 * std::log(r[i])) * std::cos(2.0 * PI * r[i + 1]);
+                x[x_lo + i] = std::sqrt(-2.0 * std::log(r[i])) * std::sin(2.0 * PI * r[i + 1]);
+            }
+        } else {
+            x_hi = x_hi - 1;
+            const int m = (x_hi - x_lo + 1) / 2 + 1;
+            std::vector<double> r(2 * m);
+            for (auto &v : r) v = uniform();
+            for (int i = 0; i <= 2 * m - 4; i += 2) {
+                x[x_lo + i - 1] = std::sqrt(-2.0 * std::log(r[i])) * std::cos(2.0 * PI * r[i + 1]);
+                x[x_lo + i] = std::sqrt(-2.0 * std::log(r[i])) * std::sin(2.0 * PI * r[i + 1]);
+            }
+            const int i = 2 * m - 2;
+            x[x_lo + i - 1] = std::sqrt(-2.0 * std::log(r[i])) * std::cos(2.0 * PI * r[i + 1]);
+            y = std::sqrt(-2.0 * std::log(r[i])) * std::sin(2.0 * PI * r[i + 1]);
+            saved = 1;
+        }
+    }
+};
+
+// lower Cholesky factor of an n x n SPD matrix (what tmpmat.llt().matrixL() returns, MALA.cpp:344)
+bool cholesky(const double *A, int n, double *L)
+{
+    std::memset(L, 0, sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; j++) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        const double ljj = std::sqrt(d);
+        L[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; i++) {
+            double v = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = v / ljj;
+        }
+    }
+    return true;
+}
+
+double min1(double e)   // VectorXd(1., e).minCoeff() with the scalar visitor: NaN never replaces 1
+{
+    double r = 1.0;
+    if (e < r) r = e;
+    return r;
+}
+
+int hip_eval_trampoline(void *user, int32_t n, int32_t np, const double *params, const double *T, double *logL, int32_t *status)
+{
+    return tamcmc_eval_batch(static_cast<tamcmc_ctx *>(user), n, np, params, T, logL, nullptr, 0, nullptr, nullptr, status);
+}
+
+}  // namespace
+
+struct tamcmc_sampler {
+    tamcmc_sampler_cfg cfg{};
+    tamcmc_eval_fn eval = nullptr;
+    void *eval_user = nullptr;
+    PriorSpec prior;
+    int Nparams = 0, Nvars = 0, nloc = 0;
+    std::vector<int32_t> index_to_relax;
+    std::vector<double> T;                       // global ladder
+    // current state (local chains)
+    std::vector<double> params, vars, logL, logPrior, logPost, Pmove;
+    std::vector<uint8_t> moved;
+    // proposal (local chains)
+    std::vector<double> covar, sigma, mu, Lchol;
+    std::vector<uint8_t> chol_valid;
+    // scratch
+    std::vector<double> p_prop, v_prop, L_prop, u_mh, z;
+    std::vector<int32_t> status;
+    Rng rng;
+    int64_t iter = 0;
+    int64_t bad_chol = 0;
+};
+
+static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, tamcmc_eval_fn eval, void *eval_user,
+                         int32_t Nparams, const int32_t plength[11], const double *inputs, const int32_t *relax,
+                         const int32_t *sw, const double *pp, int32_t nrows, const double extra[4], const double *err)
+{
+    if (!out || !cfg || !eval || !plength || !inputs || !relax || !sw || !extra || !err) return TAMCMC_E_INVALID;
+    if (cfg->Nchains < 1 || cfg->Nchains_local < 1 || cfg->chain_offset < 0 ||
+        cfg->chain_offset + cfg->Nchains_local > cfg->Nchains) return TAMCMC_E_INVALID;
+    if (cfg->n_learn < 0 || cfg->n_learn > TAMCMC_MAX_LEARN || nrows < 0 || (nrows > 0 && !pp)) return TAMCMC_E_INVALID;
+    int sum = 0;
+    for (int i = 0; i < 11; i++) sum += plength[i];
+    if (sum != Nparams) return TAMCMC_E_INVALID;
+    tamcmc_sampler *s = new (std::nothrow) tamcmc_sampler();
+    if (!s) return TAMCMC_E_NOMEM;
+    s->cfg = *cfg;
+    s->eval = eval; s->eval_user = eval_user;
+    s->Nparams = Nparams;
+    s->nloc = cfg->Nchains_local;
+    for (int i = 0; i < Nparams; i++) if (relax[i] == 1) s->index_to_relax.push_back(i);
+    s->Nvars = (int)s->index_to_relax.size();
+    if (s->Nvars < 1) { delete s; return TAMCMC_E_INVALID; }
+    PriorSpec &P = s->prior;
+    P.fct = cfg->prior_fct_switch; P.Nparams = Nparams; P.nrows = nrows;
+    std::memcpy(P.plength, plength, sizeof(int) * 11);
+    P.sw.assign(sw, sw + Nparams);
+    if (nrows > 0) P.pp.assign(pp, pp + (size_t)nrows * Nparams);
+    std::memcpy(P.extra, extra, sizeof(double) * 4);
+    const int n = s->nloc, nv = s->Nvars;
+    s->T.resize(cfg->Nchains);
+    for (int m = 0; m < cfg->Nchains; m++) s->T[m] = std::pow(cfg->lambda_temp, m);   // MALA.cpp:103
+    s->params.resize((size_t)n * Nparams); s->vars.resize((size_t)n * nv);
+    for (int m = 0; m < n; m++) {
+        std::memcpy(&s->params[(size_t)m * Nparams], inputs, sizeof(double) * Nparams);
+        for (int k = 0; k < nv; k++) s->vars[(size_t)m * nv + k] = inputs[s->index_to_relax[k]];
+    }
+    s->logL.assign(n, 0); s->logPrior.assign(n, 0); s->logPost.assign(n, 0); s->Pmove.assign(n, 0); s->moved.assign(n, 0);
+    // init_proposal, MALA.cpp:246-289
+    s->covar.assign((size_t)n * nv * nv, 0.0); s->sigma.resize(n); s->mu.resize((size_t)n * nv);
+    s->Lchol.assign((size_t)n * nv * nv, 0.0); s->chol_valid.assign(n, 0);
+    for (int m = 0; m < n; m++) {
+        for (int k = 0; k < nv; k++) {
+            s->covar[((size_t)m * nv + k) * nv + k] = err[k] * err[k];
+            s->mu[(size_t)m * nv + k] = s->vars[(size_t)m * nv + k];
+        }
+        s->sigma[m] = std::pow(2.38, 2) * std::pow(s->T[cfg->chain_offset + m], 0.2) / nv;
+    }
+    s->p_prop.resize((size_t)n * Nparams); s->v_prop.resize((size_t)n * nv); s->L_prop.resize(n);
+    s->u_mh.resize(n); s->z.resize(nv); s->status.resize(n);
+    s->rng.g.seed(cfg->seed);
+    *out = s;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_create(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, tamcmc_eval_fn eval, void *eval_user,
+                                     int32_t Nparams, const int32_t plength[11], const double *inputs, const int32_t *relax,
+                                     const int32_t *sw, const double *pp, int32_t nrows, const double extra[4], const double *err)
+{
+    return sampler_alloc(out, cfg, eval, eval_user, Nparams, plength, inputs, relax, sw, pp, nrows, extra, err);
+}
+
+extern "C" int tamcmc_sampler_create_hip(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, tamcmc_ctx *ctx,
+                                         int32_t Nparams, const int32_t plength[11], const double *inputs, const int32_t *relax,
+                                         const int32_t *sw, const double *pp, int32_t nrows, const double extra[4], const double *err)
+{
+    if (!ctx) return TAMCMC_E_INVALID;
+    return sampler_alloc(out, cfg, hip_eval_trampoline, ctx, Nparams, plength, inputs, relax, sw, pp, nrows, extra, err);
+}
+
+extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; return TAMCMC_OK; }
+extern "C" int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s) { return s ? s->iter : -1; }
+extern "C" int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->Nvars : -1; }
+
+// model_def.cpp:139-143 + :358-367 for the starting point of every chain
+extern "C" int tamcmc_sampler_init(tamcmc_sampler *s)
+{
+    if (!s) return TAMCMC_E_INVALID;
+    const int n = s->nloc;
+    int rc = s->eval(s->eval_user, n, s->Nparams, s->params.data(), &s->T[s->cfg.chain_offset], s->logL.data(), s->status.data());
+    if (rc != TAMCMC_OK) return rc;
+    int perr = 0;
+    for (int m = 0; m < n; m++) {
+        s->logPrior[m] = (double)log_prior(s->prior, &s->params[(size_t)m * s->Nparams], &perr);
+        s->logPost[m] = s->logL[m] + s->logPrior[m];
+    }
+    return perr ? TAMCMC_E_INVALID : TAMCMC_OK;
+}
+
+// MALA.cpp:292-315 with the projections of :135-176
+static void update_proposal(tamcmc_sampler *s, int m, double gamma, double acceptance)
+{
+    const int nv = s->Nvars;
+    double *mu = &s->mu[(size_t)m * nv], *C = &s->covar[(size_t)m * nv * nv];
+    const double *v = &s->vars[(size_t)m * nv];
+    const double A1 = s->cfg.A1;
+    // mu <- p3(mu + gamma (v - mu))
+    double nrm = 0.0;
+    for (int k = 0; k < nv; k++) { mu[k] = mu[k] + gamma * (v[k] - mu[k]); nrm += mu[k] * mu[k]; }
+    nrm = std::sqrt(nrm);
+    if (!(nrm <= A1)) for (int k = 0; k < nv; k++) mu[k] = mu[k] * A1 / nrm;
+    // Sigma <- p2(Sigma + gamma ((v - mu)(v - mu)^T - Sigma)), with the ALREADY updated mu
+    double fn = 0.0;
+    for (int i = 0; i < nv; i++)
+        for (int j = 0; j < nv; j++) {
+            const double mat = (v[i] - mu[i]) * (v[j] - mu[j]);
+            double &c = C[(size_t)i * nv + j];
+            c = c + gamma * (mat - c);
+            fn += c * c;
+        }
+    fn = std::sqrt(fn);
+    if (!(fn <= A1)) for (size_t e = 0; e < (size_t)nv * nv; e++) C[e] = C[e] * A1 / fn;
+    // sigma <- p1(sigma + gamma (acceptance - target))
+    ld x = (ld)s->sigma[m] + (ld)gamma * ((ld)acceptance - (ld)s->cfg.target_acceptance);
+    ld sp = x;
+    if (x < s->cfg.epsilon1) sp = s->cfg.epsilon1;
+    if (x > A1) sp = A1;
+    s->sigma[m] = (double)sp;
+    s->chol_valid[m] = 0;
+}
+
+static bool learning_now(const tamcmc_sampler *s, int64_t i, int64_t *period)
+{
+    bool logic = false;
+    int which = 0;
+    for (int l = 0; l + 1 < s->cfg.n_learn; l++) {                 // MALA.cpp:644-650
+        const bool in = (i >= s->cfg.Nt_learn[l]) && (i < s->cfg.Nt_learn[l + 1]);
+        logic = logic || in;
+        if (in) which = l;
+    }
+    *period = (s->cfg.n_learn >= 2) ? s->cfg.periods_learn[which] : 1;
+    return logic;
+}
+
+extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
+{
+    if (!s) return TAMCMC_E_INVALID;
+    const int n = s->nloc, nv = s->Nvars, np = s->Nparams, off = s->cfg.chain_offset;
+    const int64_t i = s->iter;
+    const double gamma = s->cfg.c0 / (1. + (double)i);             // MALA.cpp:630
+    std::vector<double> tmp((size_t)nv * nv);
+    // 1. proposals, in the reference's draw order: for each chain, u then z (MALA.cpp:451,465,346)
+    for (int g = 0; g < s->cfg.Nchains; g++) {
+        const double u = s->rng.uniform();
+        s->rng.normals(nv, s->z.data());
+        const int m = g - off;
+        if (m < 0 || m >= n) continue;
+        s->u_mh[m] = u;
+        if (!s->chol_valid[m]) {
+            const double *C = &s->covar[(size_t)m * nv * nv];
+            for (int a = 0; a < nv; a++)
+                for (int b = 0; b < nv; b++)
+                    tmp[(size_t)a * nv + b] = (C[(size_t)a * nv + b] + (a == b ? s->cfg.epsilon2 : 0.0)) * s->sigma[m];   // :342
+            if (!cholesky(tmp.data(), nv, &s->Lchol[(size_t)m * nv * nv])) s->bad_chol++;
+            s->chol_valid[m] = 1;
+        }
+        const double *Lc = &s->Lchol[(size_t)m * nv * nv];
+        for (int a = 0; a < nv; a++) {
+            double acc = 0.0;
+            for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * s->z[b];
+            s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + acc;             // :349
+        }
+        std::memcpy(&s->p_prop[(size_t)m * np], &s->params[(size_t)m * np], sizeof(double) * np);
+        for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
+    }
+    // 2. the hot path: every local chain in one call
+    int rc = s->eval(s->eval_user, n, np, s->p_prop.data(), &s->T[off], s->L_prop.data(), s->status.data());
+    if (rc != TAMCMC_OK) return rc;
+    // 3. accept / reject and adaptation, MALA.cpp:475-534, :641-652
+    int64_t period = 1;
+    const bool learn = learning_now(s, i, &period);
+    int perr = 0;
+    for (int m = 0; m < n; m++) {
+        const double lpr = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+        const double lpo = s->L_prop[m] + lpr;
+        double r;
+        if (!std::isnan(s->L_prop[m])) {
+            if (lpo == -std::numeric_limits<double>::infinity()) r = 0.;
+            else r = min1(std::exp(lpo - s->logPost[m]));
+        } else {
+            r = 0.;
+        }
+        if (s->u_mh[m] <= r) {
+            std::memcpy(&s->params[(size_t)m * np], &s->p_prop[(size_t)m * np], sizeof(double) * np);
+            std::memcpy(&s->vars[(size_t)m * nv], &s->v_prop[(size_t)m * nv], sizeof(double) * nv);
+            s->logL[m] = s->L_prop[m]; s->logPrior[m] = lpr; s->logPost[m] = lpo;
+            s->moved[m] = 1;
+        } else {
+            s->moved[m] = 0;
+        }
+        s->Pmove[m] = r;
+        if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
+    }
+    return perr ? TAMCMC_E_INVALID : TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s)
+{
+    if (!s || s->cfg.dN_mixing <= 0 || s->cfg.Nchains < 2) return 0;
+    return (s->iter % s->cfg.dN_mixing == 0 && s->iter != 0) ? 1 : 0;   // MALA.cpp:676
+}
+
+extern "C" int tamcmc_sampler_pt_draw(tamcmc_sampler *s, int32_t *A, double *u)
+{
+    if (!s || !A || !u) return TAMCMC_E_INVALID;
+    *u = s->rng.uniform();                                   // MALA.cpp:384
+    *A = (int32_t)(s->rng.g.next() % (s->cfg.Nchains - 1));  // random_int_vals(0, Nchains-1), :390 and :178-187
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_pt_record_size(const tamcmc_sampler *s) { return s ? 4 + s->Nparams + s->Nvars : -1; }
+
+extern "C" int tamcmc_sampler_pt_export(const tamcmc_sampler *s, int32_t chain, double *rec)
+{
+    if (!s || !rec) return TAMCMC_E_INVALID;
+    const int m = chain - s->cfg.chain_offset;
+    if (m < 0 || m >= s->nloc) return TAMCMC_E_INVALID;
+    rec[0] = s->logL[m]; rec[1] = s->logPrior[m]; rec[2] = s->moved[m]; rec[3] = s->Pmove[m];
+    std::memcpy(rec + 4, &s->params[(size_t)m * s->Nparams], sizeof(double) * s->Nparams);
+    std::memcpy(rec + 4 + s->Nparams, &s->vars[(size_t)m * s->Nvars], sizeof(double) * s->Nvars);
+    return TAMCMC_OK;
+}
+
+// MALA.cpp:393-434 for the end(s) of the pair (A, A+1) owned here.  recA / recB: records of chain A and
+// A+1 BEFORE the swap (own export or the peer's).
+static void pt_apply(tamcmc_sampler *s, int A, double u, const double *recA, const double *recB, int32_t *swapped, double *r_out)
+{
+    const int B = A + 1, np = s->Nparams, nv = s->Nvars, off = s->cfg.chain_offset;
+    const double TA = s->T[A], TB = s->T[B];
+    const double L_A = recA[0], L_B = recB[0];
+    const ld logL_A_TB = (ld)(L_A * TA / TB), logL_B_TA = (ld)(L_B * TB / TA);
+    const double r_T = min1(std::exp((double)(logL_A_TB + logL_B_TA - (ld)L_A - (ld)L_B)));
+    const bool sw = (u <= r_T);
+    if (sw) {
+        const int a = A - off, b = B - off;
+        if (a >= 0 && a < s->nloc) {   // A <- B
+            std::memcpy(&s->params[(size_t)a * np], recB + 4, sizeof(double) * np);
+            std::memcpy(&s->vars[(size_t)a * nv], recB + 4 + np, sizeof(double) * nv);
+            s->logL[a] = (double)logL_B_TA;
+            s->logPrior[a] = recB[1];
+            s->logPost[a] = (double)(logL_B_TA + (ld)recB[1]);
+            s->moved[a] = (uint8_t)recB[2]; s->Pmove[a] = recB[3];
+        }
+        if (b >= 0 && b < s->nloc) {   // B <- A ; logPosterior[B] uses logPrior[ind_A] AFTER it was overwritten (quirk A.6-8)
+            std::memcpy(&s->params[(size_t)b * np], recA + 4, sizeof(double) * np);
+            std::memcpy(&s->vars[(size_t)b * nv], recA + 4 + np, sizeof(double) * nv);
+            s->logL[b] = (double)logL_A_TB;
+            s->logPrior[b] = recA[1];
+            s->logPost[b] = (double)(logL_A_TB + (ld)recB[1]);
+            s->moved[b] = (uint8_t)recA[2]; s->Pmove[b] = recA[3];
+        }
+    }
+    if (swapped) *swapped = sw ? 1 : 0;
+    if (r_out) *r_out = r_T;
+}
+
+extern "C" int tamcmc_sampler_pt_local(tamcmc_sampler *s, int32_t A, double u, int32_t *swapped, double *r_T)
+{
+    if (!s || A < 0 || A + 1 >= s->cfg.Nchains) return TAMCMC_E_INVALID;
+    std::vector<double> ra(tamcmc_sampler_pt_record_size(s)), rb(ra.size());
+    if (tamcmc_sampler_pt_export(s, A, ra.data()) != TAMCMC_OK || tamcmc_sampler_pt_export(s, A + 1, rb.data()) != TAMCMC_OK)
+        return TAMCMC_E_INVALID;
+    pt_apply(s, A, u, ra.data(), rb.data(), swapped, r_T);
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_pt_import(tamcmc_sampler *s, int32_t A, double u, const double *peer, int32_t *swapped, double *r_T)
+{
+    if (!s || !peer || A < 0 || A + 1 >= s->cfg.Nchains) return TAMCMC_E_INVALID;
+    const int off = s->cfg.chain_offset;
+    const bool ownA = (A >= off && A < off + s->nloc), ownB = (A + 1 >= off && A + 1 < off + s->nloc);
+    if (ownA == ownB) return TAMCMC_E_INVALID;   // must own exactly one end
+    std::vector<double> mine(tamcmc_sampler_pt_record_size(s));
+    tamcmc_sampler_pt_export(s, ownA ? A : A + 1, mine.data());
+    if (ownA) pt_apply(s, A, u, mine.data(), peer, swapped, r_T);
+    else      pt_apply(s, A, u, peer, mine.data(), swapped, r_T);
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_end_iteration(tamcmc_sampler *s) { if (!s) return TAMCMC_E_INVALID; s->iter++; return TAMCMC_OK; }
+
+extern "C" int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, int32_t *swap_hist)
+{
+    if (!s || s->nloc != s->cfg.Nchains) return TAMCMC_E_INVALID;   // single process only
+    for (int64_t k = 0; k < n_iter; k++) {
+        int rc = tamcmc_sampler_mh_step(s);
+        if (rc != TAMCMC_OK) return rc;
+        if (moved_hist) std::memcpy(moved_hist + (size_t)k * s->nloc, s->moved.data(), s->nloc);
+        int32_t sh = -1;
+        if (tamcmc_sampler_pt_due(s)) {
+            int32_t A, swapped; double u, r;
+            tamcmc_sampler_pt_draw(s, &A, &u);
+            rc = tamcmc_sampler_pt_local(s, A, u, &swapped, &r);
+            if (rc != TAMCMC_OK) return rc;
+            sh = 2 * A + swapped;
+        }
+        if (swap_hist) swap_hist[k] = sh;
+        s->iter++;
+    }
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_get(const tamcmc_sampler *s, int32_t which, double *out, int64_t cap)
+{
+    if (!s || !out) return TAMCMC_E_INVALID;
+    const std::vector<double> *v = nullptr;
+    std::vector<double> tmp;
+    switch (which) {
+    case 0: v = &s->vars; break;
+    case 1: v = &s->params; break;
+    case 2: v = &s->logL; break;
+    case 3: v = &s->logPrior; break;
+    case 4: v = &s->logPost; break;
+    case 5: v = &s->Pmove; break;
+    case 6: v = &s->sigma; break;
+    case 7: v = &s->mu; break;
+    case 8: v = &s->covar; break;
+    case 9: tmp.assign(s->T.begin() + s->cfg.chain_offset, s->T.begin() + s->cfg.chain_offset + s->nloc); v = &tmp; break;
+    default: return TAMCMC_E_INVALID;
+    }
+    if ((int64_t)v->size() > cap) return TAMCMC_E_INVALID;
+    std::memcpy(out, v->data(), sizeof(double) * v->size());
+    return TAMCMC_OK;
+}
+
+extern "C" double tamcmc_logP_primitive(int32_t id, const double p[4], double x)
+{
+    int err = 0;
+    return (double)primitive(id, p, 4, x, &err);
+}
+
+extern "C" double tamcmc_log_prior(int32_t fct, int32_t Nparams, const double *params, const int32_t plength[11],
+                                   const int32_t *sw, const double *pp, int32_t nrows, const double extra[4], int32_t *error)
+{
+    PriorSpec S;
+    S.fct = fct; S.Nparams = Nparams; S.nrows = nrows;
+    std::memcpy(S.plength, plength, sizeof(int) * 11);
+    S.sw.assign(sw, sw + Nparams);
+    if (nrows > 0) S.pp.assign(pp, pp + (size_t)nrows * Nparams);
+    std::memcpy(S.extra, extra, sizeof(double) * 4);
+    int err = 0;
+    const double v = (double)log_prior(S, params, &err);
+    if (error) *error = err;
+    return v;
+}
+
+extern "C" void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out)
+{
+    GlibcRand g;
+    g.seed(seed);
+    for (int i = 0; i < n; i++) out[i] = g.next();
+}

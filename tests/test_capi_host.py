@@ -11,8 +11,8 @@ import workloads as W
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "tamcmc_accel.h")).read()
+def declared_symbols(header="tamcmc_accel.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(tamcmc_[a-z_]+)\s*\(", txt)))
 
@@ -25,6 +25,10 @@ def test_library_exports_every_declared_symbol(accel_mod):
         assert hasattr(lib, n), n
     assert set(names) == set(accel_mod.capi.EXPORTS)
     assert accel_mod.capi.version().startswith("tamcmc_accel")
+    sampler_names = [n for n in declared_symbols("tamcmc_sampler.h") if n not in ("tamcmc_eval_fn", "tamcmc_eval_batch")]
+    assert len(sampler_names) >= 18
+    for n in sampler_names:
+        assert hasattr(lib, n), n
 
 
 def test_strerror_covers_codes(accel_mod):
