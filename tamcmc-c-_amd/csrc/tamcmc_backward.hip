@@ -272,32 +272,44 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         double *pv = pair_val + nm * TM_NPAIR;
         int np = 0;
         if (L.family != TM_FAM_GAUSS) {
-            const double *S = s_S;
             const int id = L.model_case, s0 = L.s, q = L.q;
+            // every LDS read first (independent, pipelined), then arithmetic, then the pair stores: this thread
+            // runs alone, so a load issued after a possibly-aliasing store would cost a full LDS round trip each
+            double S[TM_NSHARED], dr[9], ps[8], pqv[9], pVv[3];
+#pragma unroll
+            for (int i = 0; i < TM_NSHARED; i++) S[i] = s_S[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) ps[i] = (s0 + i < L.Nparams) ? p[s0 + i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) pqv[i] = (q + i < L.Nparams) ? p[q + i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) pVv[i] = (L.Nmax + i < L.Nparams) ? p[L.Nmax + i] : 0.0;
+            dr[0] = C.dratios[1][1]; dr[1] = C.dratios[1][2];
+            dr[2] = C.dratios[2][2]; dr[3] = C.dratios[2][3]; dr[4] = C.dratios[2][4];
+            dr[5] = C.dratios[3][3]; dr[6] = C.dratios[3][4]; dr[7] = C.dratios[3][5]; dr[8] = C.dratios[3][6];
             pi[np] = s0 + 1; pv[np] = S[SL_ETA]; np++;
             pi[np] = s0 + 2; pv[np] = S[SL_A3]; np++;
             pi[np] = s0 + 5; pv[np] = S[SL_ASYM]; np++;
             if (id == 6) {
-                pi[np] = s0; pv[np] = tm_sign(p[s0]) * S[SL_FS1]; np++;
-                pi[np] = s0 + 6; pv[np] = tm_sign(p[s0 + 6]) * S[SL_FS2]; np++;
+                pi[np] = s0; pv[np] = tm_sign(ps[0]) * S[SL_FS1]; np++;
+                pi[np] = s0 + 6; pv[np] = tm_sign(ps[6]) * S[SL_FS2]; np++;
             }
-            // inclination adjoint from the ratio adjoints
+            // inclination adjoint from the ratio adjoints (slots SL_RATIO.. are in (l, |m|) order like dr[])
             double adj_inc = 0.0;
-            for (int l = 1; l <= 3; l++)
-                for (int am = 0; am <= l; am++) adj_inc += S[tm_ratio_slot(l, am)] * C.dratios[l][l + am];
+#pragma unroll
+            for (int t = 0; t < 9; t++) adj_inc += S[SL_RATIO + t] * dr[t];
             if (id == 12) {
-                const int base[4] = {0, 0, 2, 5};
-                for (int l = 1; l <= L.lmax; l++)
-                    for (int am = 0; am <= l; am++) {
-                        pi[np] = q + base[l] + am; pv[np] = tm_sign(p[q + base[l] + am]) * S[tm_ratio_slot(l, am)]; np++;
-                    }
+                const int nr = (L.lmax >= 3) ? 9 : (L.lmax == 2) ? 5 : (L.lmax == 1) ? 2 : 0;
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    if (t < nr) { pi[np] = q + t; pv[np] = tm_sign(pqv[t]) * S[SL_RATIO + t]; np++; }
             }
             if (id == 2 || id == 9 || id == 10 || id == 11) {
-                const double pa = p[s0 + 3], pb = p[s0 + 4], r2 = pa * pa + pb * pb;
+                const double pa = ps[3], pb = ps[4], r2 = pa * pa + pb * pb;
                 pi[np] = s0 + 3; pv[np] = 2.0 * pa * S[SL_A1] + adj_inc * (180. / PI) * (-pb / r2); np++;
                 pi[np] = s0 + 4; pv[np] = 2.0 * pb * S[SL_A1] + adj_inc * (180. / PI) * (pa / r2); np++;
             } else {
-                if (id == 3 || id == 12 || id == 13 || id == 14) { pi[np] = s0; pv[np] = tm_sign(p[s0]) * S[SL_A1]; np++; }
+                if (id == 3 || id == 12 || id == 13 || id == 14) { pi[np] = s0; pv[np] = tm_sign(ps[0]) * S[SL_A1]; np++; }
                 if (id == 3 || id == 6 || id == 7 || id == 8) { pi[np] = q; pv[np] = adj_inc; np++; }
             }
             double adj_V[4] = {0.0, S[SL_V], S[SL_V + 1], S[SL_V + 2]};
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                 }
             }
             if (L.family == TM_FAM_GLOBAL && id != 13)
-                for (int l = 1; l <= L.lmax; l++) { pi[np] = L.Nmax + l - 1; pv[np] = tm_sign(p[L.Nmax + l - 1]) * adj_V[l]; np++; }
+                for (int l = 1; l <= L.lmax; l++) { pi[np] = L.Nmax + l - 1; pv[np] = tm_sign(pVv[l - 1]) * adj_V[l]; np++; }
         }
     }
     if (tid == 64) {   // noise terms on another wave, concurrently with the chain-level work of thread 0
@@ -361,23 +373,33 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #endif
 
     // ---------------- phase 3: gather per variable, in pair order ----------------
-    for (int k = tid; k < Nvars; k += TM_BW_THREADS) {
-        const int target = relax[k];
-        double acc = 0.0;
-        // pair order is preserved; eight loads in flight per step (a plain loop is one LDS latency per pair)
-        for (int e0 = 0; e0 < npairs_max; e0 += 8) {
-            int id[8];
-            double v[8];
+    // four lanes per variable, each scanning a contiguous quarter of the pairs in order; the four partial sums are
+    // then combined in a fixed order (bitwise reproducible; a single lane per variable costs one LDS latency chain
+    // over all pairs)
+    {
+        const int seg = tid & 3;
+        const int per = (npairs_max + 3) / 4;
+        const int e_lo = seg * per, e_hi = (e_lo + per < npairs_max) ? e_lo + per : npairs_max;
+        for (int k0 = 0; k0 < Nvars; k0 += TM_BW_THREADS / 4) {
+            const int k = k0 + (tid >> 2);
+            const int target = (k < Nvars) ? relax[k] : -2;
+            double acc = 0.0;
+            for (int e0 = e_lo; e0 < e_hi; e0 += 8) {
+                int id[8];
+                double v[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int e = (e0 + q < npairs_max) ? e0 + q : npairs_max - 1;
-                id[q] = (e0 + q < npairs_max) ? pair_idx[e] : -1;
-                v[q] = pair_val[e];
+                for (int q = 0; q < 8; q++) {
+                    const bool in = e0 + q < e_hi;
+                    const int e = in ? e0 + q : e_lo;
+                    id[q] = in ? pair_idx[e] : -1;
+                    v[q] = pair_val[e];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += (id[q] == target) ? v[q] : 0.0;
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) acc += (id[q] == target) ? v[q] : 0.0;
+            const double a1 = __shfl_down(acc, 1, 4), a2 = __shfl_down(acc, 2, 4), a3 = __shfl_down(acc, 3, 4);
+            if (seg == 0 && k < Nvars) grad[(size_t)chain * Nvars + k] = ((acc + a1) + a2) + a3;
         }
-        grad[(size_t)chain * Nvars + k] = acc;
     }
 }
 
