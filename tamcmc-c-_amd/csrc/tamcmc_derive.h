@@ -66,6 +66,16 @@ __device__ __forceinline__ int tm_factorial(int n)
     return t;
 }
 
+// combi(n, r) = n! / (n-r)! / r! of function_rot.cpp:95-97 for n <= 6, without integer divisions by variables
+__device__ __forceinline__ int tm_combi(int n, int r)
+{
+    if (r > n - r) r = n - r;
+    if (r <= 0) return (r == 0) ? 1 : 0;
+    if (r == 1) return n;
+    if (r == 2) return n * (n - 1) / 2;
+    return n * (n - 1) * (n - 2) / 6;
+}
+
 // d^l_{m1,m2}(beta) and its derivative with respect to beta (radians); function_rot.cpp:81-93
 __device__ inline double tm_dmm(int l, int m1, int m2, double beta, double *dbeta)
 {
@@ -73,8 +83,7 @@ __device__ inline double tm_dmm(int l, int m1, int m2, double beta, double *dbet
     double sum = 0.0, dsum = 0.0;
     for (int s = 0; s <= l - m1; s++) {
         const int ec = 2 * s + m1 + m2, es = 2 * l - 2 * s - m1 - m2;
-        double coef = (double)(tm_factorial(l + m2) / tm_factorial(l + m2 - (l - m1 - s)) / tm_factorial(l - m1 - s)) *
-                      (double)(tm_factorial(l - m2) / tm_factorial(l - m2 - s) / tm_factorial(s));
+        double coef = (double)tm_combi(l + m2, l - m1 - s) * (double)tm_combi(l - m2, s);   // function_rot.cpp:85
         if ((l - m1 - s) & 1) coef = -coef;
         sum = sum + coef * tm_ipow(cb, ec) * tm_ipow(sb, es);
         // d/dbeta [c^ec s^es] = 0.5 * (es c^(ec+1) s^(es-1) - ec c^(ec-1) s^(es+1))

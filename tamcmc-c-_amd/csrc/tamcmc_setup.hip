@@ -9,7 +9,8 @@
 #include "tamcmc_dev.h"
 #include "tamcmc_derive.h"
 
-__global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
+#define TM_SETUP_THREADS 128   // wave 0: chain record + multiplets; wave 1 lane 0: noise record, concurrently
+__global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
                                                           TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
                                                           TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux)
 {
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
     const int tid = threadIdx.x;
     extern __shared__ double s_p[];   // this chain's params row: every later access is an LDS read
     double *p = s_p;
-    for (int e = tid; e < L.Nparams; e += 64) p[e] = params[(size_t)chain * L.Nparams + e];
+    for (int e = tid; e < L.Nparams; e += TM_SETUP_THREADS) p[e] = params[(size_t)chain * L.Nparams + e];
     __shared__ TmChain C;
     __shared__ TmMultFull s_M[64];    // per-lane scratchpad: dynamically indexed fields stay out of scratch memory
     __shared__ int s_status;
@@ -31,13 +32,41 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
         tm_derive_chain_coop(L, p, C, tid);
         // keep the chain record for the backward kernel (gradient path)
         if (chain_rec != nullptr)
-            for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += 64)
+            for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_SETUP_THREADS)
                 reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
     } else {
         __syncthreads();
     }
 
-    if (L.family != TM_FAM_GAUSS) {
+    __shared__ TmNoise s_N;           // N.H[N.nh] is dynamically indexed: LDS, not scratch
+    if (tid == 64) {
+        TmNoise &N = s_N;
+        for (int k = 0; k < TM_MAXH; k++) { N.H[k] = 0.0; N.lt[k] = 0.0; N.p[k] = 0.0; }
+        N.N0 = 0.0; N.gA = 0.0; N.gnu0 = 0.0; N.gs2 = 1.0; N.nh = 0; N.has_gauss = 0; N.pad = 0;
+        int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
+        bool take_abs = true;
+        if (L.model_case == 0) {
+            // model_Test_Gaussian, models.cpp:2021-2034 (no abs anywhere)
+            N.has_gauss = 1; N.gA = p[0]; N.gnu0 = p[2]; N.gs2 = p[1] * p[1];
+            z = 3; Nnoise = 1; nharvey = 0; take_abs = false;
+        } else if (L.model_case == 1) {
+            // model_Harvey_Gaussian, models.cpp:1968-1992
+            N.has_gauss = 1; N.gA = fabs(p[0]); N.gnu0 = p[2]; N.gs2 = fabs(p[1]) * fabs(p[1]);
+            z = 3; Nnoise = 4; nharvey = 1;
+        }
+        double extra = 0.0;
+        for (int k = 0; k < nharvey; k++) {
+            const double H = fabs(p[z + 3 * k]), tau = fabs(p[z + 3 * k + 1]), pw = fabs(p[z + 3 * k + 2]);
+            if (tau != 0) {                           // noise_models.cpp:31
+                if (pw == 0) { extra = extra + H * 0.5; continue; } // (..)^0 = 1 for every bin
+                N.H[N.nh] = H; N.lt[N.nh] = log((1e-3) * tau); N.p[N.nh] = pw; N.nh++;
+            }
+        }
+        const double n0 = p[z + Nnoise - 1];
+        N.N0 = (take_abs ? fabs(n0) : n0) + extra;
+    }
+
+    if (L.family != TM_FAM_GAUSS && tid < 64) {
         for (int j = tid; j < L.n_mult; j += 64) {
             TmMultFull &M = s_M[tid];
             tm_derive_mult(L, C, p, j, M);
@@ -65,42 +94,17 @@ __global__ __launch_bounds__(64) void tamcmc_setup_kernel(TmLayout L, const doub
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
     return;   // timing-only build
 #endif
-
-    __shared__ TmNoise s_N;           // N.H[N.nh] is dynamically indexed: LDS, not scratch
-    if (tid == 0) {
-        TmNoise &N = s_N;
-        for (int k = 0; k < TM_MAXH; k++) { N.H[k] = 0.0; N.lt[k] = 0.0; N.p[k] = 0.0; }
-        N.N0 = 0.0; N.gA = 0.0; N.gnu0 = 0.0; N.gs2 = 1.0; N.nh = 0; N.has_gauss = 0; N.pad = 0;
-        int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
-        bool take_abs = true;
-        if (L.model_case == 0) {
-            // model_Test_Gaussian, models.cpp:2021-2034 (no abs anywhere)
-            N.has_gauss = 1; N.gA = p[0]; N.gnu0 = p[2]; N.gs2 = p[1] * p[1];
-            z = 3; Nnoise = 1; nharvey = 0; take_abs = false;
-        } else if (L.model_case == 1) {
-            // model_Harvey_Gaussian, models.cpp:1968-1992
-            N.has_gauss = 1; N.gA = fabs(p[0]); N.gnu0 = p[2]; N.gs2 = fabs(p[1]) * fabs(p[1]);
-            z = 3; Nnoise = 4; nharvey = 1;
-        }
-        double extra = 0.0;
-        for (int k = 0; k < nharvey; k++) {
-            const double H = fabs(p[z + 3 * k]), tau = fabs(p[z + 3 * k + 1]), pw = fabs(p[z + 3 * k + 2]);
-            if (tau != 0) {                           // noise_models.cpp:31
-                if (pw == 0) { extra = extra + H * 0.5; continue; } // (..)^0 = 1 for every bin
-                N.H[N.nh] = H; N.lt[N.nh] = log((1e-3) * tau); N.p[N.nh] = pw; N.nh++;
-            }
-        }
-        const double n0 = p[z + Nnoise - 1];
-        N.N0 = (take_abs ? fabs(n0) : n0) + extra;
-        N.status = s_status;
-        noise[chain] = N;
+    if (tid == 64) {
+        s_N.status = s_status;
+        noise[chain] = s_N;
     }
 }
+
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise,
                     void *d_chain_rec, void *d_aux, void *stream)
 {
-    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(64), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
+    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
                        d_params, d_mult, d_noise, static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux));
     return (int)hipGetLastError();
 }

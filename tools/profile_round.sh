@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): tests, bench, rocprofv3 kernel stats and PMC passes.
+# Usage: bash tools/profile_round.sh <tag>     -> everything under gpurun_out/<tag>/
+TAG=${1:-final}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 && echo "stats ok"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1 && echo "pmc sq ok"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1 && echo "pmc fetch ok"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1 && echo "pmc write ok"
+# clock probe: long kernels (4096 chains) so that GRBM_GUI_ACTIVE / 8 / duration is a meaningful clock estimate
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_clock -- python3 $R/bench.py --steps 3 --warmup 1 --chains 4096 --no-cpu-baseline > $O/pmc_clock.log 2>&1 && echo "pmc clock ok"
+cd $R && python tools/summarize_profiles.py $O

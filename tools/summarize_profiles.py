@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_round.sh output directory into pmc_summary.json (per-kernel means over the
+64-chain launches): instruction counts, HBM traffic from FETCH_SIZE / WRITE_SIZE, estimated shader clock."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def rows(d):
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        yield from csv.DictReader(open(f))
+
+
+def main(out_dir):
+    res = collections.defaultdict(dict)
+    for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows(os.path.join(out_dir, sub)):
+            if "tamcmc" not in r["Kernel_Name"]:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                gmax = max(g for g, _, _ in v)
+                full = [(val, dur) for g, val, dur in v if g == gmax]     # drop the 1-chain model_explicit launch
+                res[k][c] = sum(x for x, _ in full) / len(full)
+                res[k].setdefault("launches", len(full))
+                res[k]["mean_ns_profiled"] = sum(d for _, d in full) / len(full)
+    clock = {}
+    for r in rows(os.path.join(out_dir, "pmc_clock")):
+        if "tamcmc_eval_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if dur > 1_000_000:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                clock.setdefault(k, []).append(float(r["Counter_Value"]) / 8.0 / dur)   # cycles per ns = GHz
+    out = {"kernels": res, "clock_GHz_long_kernels": {k: sum(v) / len(v) for k, v in clock.items()},
+           "note": "FETCH_SIZE/WRITE_SIZE are in KB (x1024 for bytes); 8-byte-per-lane loads are not calibrated for the "
+                   "gfx950 half-count effect of MI355X_MICROARCH.md, so read traffic is a lower bound up to 2x"}
+    for k, d in res.items():
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            d["hbm_bytes_per_launch"] = (d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+    json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True)[:3000])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
