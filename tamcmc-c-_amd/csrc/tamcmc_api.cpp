@@ -31,7 +31,7 @@ struct tamcmc_ctx {
     int device = 0;
     TmLayout L{};
     int K = 4, S = 2;              // likelihood only: KU bins in flight per thread, S sub-blocks -> 2048-bin tiles
-    int Kg = 4, Sg = 4;            // with gradient partials: 4096-bin tiles (pass 2 runs 2 bins at a time internally)
+    int Kg = 2, Sg = 8;            // with gradient partials: 4096-bin tiles, 2 bins in flight (3 waves per SIMD)
     int tiles = 0;                 // tiles at K
     int tiles_g = 0;               // tiles at Kg
     int tiles_max = 0;
@@ -217,7 +217,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_KU_GRAD", 1, 4, &c->Kg);
     env_int("TAMCMC_S_GRAD", 1, 16, &c->Sg);
     if (c->K == 3) c->K = 4;
-    if (c->Kg == 3) c->Kg = 4;
+    if (c->Kg == 3) c->Kg = 2;
     {
         const int64_t TB = (int64_t)TM_THREADS * c->K * c->S, TBg = (int64_t)TM_THREADS * c->Kg * c->Sg;
         c->tiles = (int)((Nx + TB - 1) / TB);

@@ -37,6 +37,12 @@
 
 #define TM_WAVES (TM_THREADS / 64)
 
+// A multiplet record addressed through the CONSTANT address space: with a wave-uniform address the compiler
+// fetches it with scalar loads (s_load_dwordx8/x16) into SGPRs, which VALU instructions take directly as one
+// operand -- no LDS read, no VGPRs for the record.  The table was written by the previous kernel (setup), so
+// it is invariant for this launch.
+typedef const __attribute__((address_space(4))) TmMult *TmMultK;
+
 // 1/x for finite, normal, positive x: v_rcp_f64 + two Newton steps (no scaling / fix-up needed
 // because every denominator here is bounded away from the subnormal and overflow ranges).
 __device__ __forceinline__ double tm_rcp(double x)
@@ -139,7 +145,7 @@ __device__ __forceinline__ double tm_mult_value(double x2, const double (&nu2)[N
 
 // Forward: add multiplet `sm` (LDS) to acc[] for KU bins.
 template <int NC, int KU, bool ASYM>
-__device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x2)[KU], const int (&bi)[KU], double (&acc)[KU])
+__device__ __forceinline__ void tm_accum_mult(TmMultK sm, const double (&x2)[KU], const int (&bi)[KU], double (&acc)[KU])
 {
     double nu2[NC], hq[NC];
 #pragma unroll
@@ -165,7 +171,7 @@ __device__ __forceinline__ void tm_accum_mult(const TmMult *sm, const double (&x
 //   g[3m+0] = sum wA r_m, g[3m+1] = sum wA d_m r_m^2, g[3m+2] = sum wA r_m^2   (d = 2x - 2nu, r = 1/E)
 //   g[3NC..3NC+2] = sum w S, sum w S a, sum w S a x   (S = un-asymmetrised multiplet sum; zero if asym == 0)
 template <int NC, int KU, bool ASYM>
-__device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__restrict__ gx, const double *s_w,
+__device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restrict__ gx, const double *s_w,
                                              int base, int S, int Nx, int tid, int lane, double *s_red_row)
 {
     constexpr int V = ASYM ? 3 * NC + 3 : 3 * NC;
@@ -230,7 +236,7 @@ __device__ __forceinline__ void tm_grad_mult(const TmMult *sm, const double *__r
 #define TM_LB_FWD 4    // resident waves per SIMD the register allocator must allow (likelihood-only kernel)
 #endif
 #ifndef TM_LB_GRAD
-#define TM_LB_GRAD 2   // same for the gradient kernel (no spills; 3 was measured slower: it spills)
+#define TM_LB_GRAD 3   // same for the gradient kernel: 155 VGPRs at KU=2 once the multiplet records live in SGPRs
 #endif
 template <int KU, bool GRAD>
 __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             acc[k] = 0.0;
         }
         for (int jj = 0; jj < nact; jj++) {
-            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + s_idx[jj];
+            TmMultK sm = (TmMultK)(gm + __builtin_amdgcn_readfirstlane(s_idx[jj]));
             const int lo = base + u * KU * TM_THREADS;
             if (lo + KU * TM_THREADS <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
             if (sm->has_asym) {
@@ -502,12 +508,29 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     // ---------------- pass 2: gradient partial sums ----------------
     if constexpr (GRAD) {
         __syncthreads();   // s_red[0] (likelihood) consumed; s_w complete
+        // noise partial sums were accumulated in pass 1 (gn_): reduce and publish them
+        {
+            static_assert(TM_NSLOTS == 16, "butterfly below assumes 16 noise slots");
+            TmBfly<TM_NSLOTS, 32>::run(gn_, lane);
+            bool valid = true;
+            const int slot = TmBfly<TM_NSLOTS, 32>::slot_of(lane, valid);
+            double *red = s_red[1][wave];   // the buffer the last multiplet did not use
+            if ((lane & 3) == 0) red[slot] = gn_[0];
+        }
+        __syncthreads();
+        if (tid < TM_NSLOTS) {
+            double t = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[1][wv][tid];
+            a.gnoise[((size_t)chain * a.tiles + tile) * TM_NSLOTS + tid] = t;
+        }
+        __syncthreads();   // s_red[1] (noise) consumed before multiplet 0 reuses it
 #if defined(TM_ABLATE) && (TM_ABLATE & 2)   // timing-only build: no multiplet pass 2 at all
         for (int jj = 0; jj < 0; jj++) {
 #else
         for (int jj = 0; jj < nact; jj++) {
 #endif
-            const TmMult *sm = reinterpret_cast<const TmMult *>(s_mult) + s_idx[jj];
+            TmMultK sm = (TmMultK)(gm + __builtin_amdgcn_readfirstlane(s_idx[jj]));
             const int nc = sm->ncomp;
             double *red = s_red[(jj + 1) & 1][wave];
             if (sm->has_asym) {
@@ -535,22 +558,6 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 }
                 a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + s_idx[jj]) * TM_GSLOTS + tid] = t;
             }
-        }
-        // noise partial sums were accumulated in pass 1 (gn_): reduce and publish them
-        {
-            static_assert(TM_NSLOTS == 16, "butterfly below assumes 16 noise slots");
-            TmBfly<TM_NSLOTS, 32>::run(gn_, lane);
-            bool valid = true;
-            const int slot = TmBfly<TM_NSLOTS, 32>::slot_of(lane, valid);
-            double *red = s_red[(nact + 1) & 1][wave];   // the buffer the last multiplet did not use
-            if ((lane & 3) == 0) red[slot] = gn_[0];
-        }
-        __syncthreads();
-        if (tid < TM_NSLOTS) {
-            double t = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[(nact + 1) & 1][wv][tid];
-            a.gnoise[((size_t)chain * a.tiles + tile) * TM_NSLOTS + tid] = t;
         }
     }
 }
