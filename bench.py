@@ -29,8 +29,6 @@ if ROOT not in sys.path:
 
 METRIC = "MALA steps/sec (all chains) + achieved HBM GB/s, 64 chains × 1e5-bin spectrum"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6   # vendor vector fp64 peak (FMA = 2 flop)
-F_ALG_LOGL = 3.7e7             # flop-equivalents per chain-step, logL only (grad ~3x)
 
 
 def main():
@@ -117,23 +115,39 @@ def main():
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
     kl_avg_s = (kl_ms / max(kl_n, 1)) * 1e-3
     achieved = bytes_per_launch / k_avg_s / 1e9
-    traffic = None
+    # PMC-derived numbers cannot be collected from inside this process: they come from the committed rocprofv3
+    # passes of this same command (tools/profile_round.sh -> profiles/hbm_traffic.json)
+    traffic, traffic_l, valu = None, None, None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("eval_grad_bytes_per_launch")
+            pm = json.load(open(tfile))
+            scale = nchains / 64.0 * args.nx / 100000.0          # the PMC passes ran 64 chains x 1e5 bins
+            traffic = pm.get("eval_grad_bytes_per_launch") * scale
+            traffic_l = pm.get("eval_logL_bytes_per_launch") * scale
+            clk = pm.get("clock_GHz", {})
+            simds = 256 * 4
+
+            def busy(insts, t_s, ghz):
+                # fp64 VALU instruction = 4 cycles on a SIMD-32 with 16 fp64 lanes/clk; fraction of all issue slots
+                return insts * scale * 4.0 / (t_s * simds * ghz * 1e9)
+            valu = {"source": "profiles/hbm_traffic.json (rocprofv3 SQ_INSTS_VALU, GRBM_GUI_ACTIVE clock estimate)",
+                    "grad_kernel_issue_frac": round(busy(pm["eval_grad_valu_insts_per_launch"], k_avg_s,
+                                                         clk.get("tamcmc_eval_kernel<4, true>", 2.4)), 3),
+                    "logL_kernel_issue_frac": round(busy(pm["eval_logL_valu_insts_per_launch"], kl_avg_s,
+                                                         clk.get("tamcmc_eval_kernel<4, false>", 2.4)), 3)}
         except Exception:
-            traffic = None
+            traffic, traffic_l, valu = None, None, None
     roofline = {
         "bound": "hbm", "kernel": "tamcmc_eval_kernel<grad>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "kernel_ms": round(k_avg_s * 1e3, 4), "launches": int(k_n),
-        "binding_roof": "fp64 VALU (SURVEY.md F6): logL-only kernel at "
-                        f"{nchains / kl_avg_s * F_ALG_LOGL / 1e12 / FP64_VALU_PEAK_TFLOPS:.3f} of {FP64_VALU_PEAK_TFLOPS} TFLOP/s "
-                        "counting SURVEY's 3.7e7 flop-equivalents per chain-step",
+        "binding_roof": "fp64 VALU, not HBM (SURVEY.md F6): x/y are shared by all chains through L2, so measured HBM "
+                        "traffic is ~10x below the algorithmic bytes; see 'valu' for the fraction of fp64 issue slots used",
+        "valu": valu,
         "logL_only": {"achieved": round(bytes_per_launch / kl_avg_s / 1e9, 2),
                       "frac": round(bytes_per_launch / kl_avg_s / 1e9 / HBM_PEAK_GBS, 5),
-                      "kernel_ms": round(kl_avg_s * 1e3, 4)},
+                      "kernel_ms": round(kl_avg_s * 1e3, 4), "traffic": traffic_l},
     }
 
     cpu = None
@@ -161,7 +175,7 @@ def main():
             "config": {"workload": "C2: model_MS_Global_a1etaa3_HarveyLike (id 2), 21 modes l=0..2, 56 params, "
                                    f"{args.nx} bins, {nchains} chains per GPU, trunc_c=20, logL + gradient over "
                                    f"{nvars} variables, params resident in HBM",
-                       "chains_total": total_chains, "bins_per_tile_grad": None, "geometry_logL": geo},
+                       "chains_total": total_chains, "geometry_logL": geo},
             "logL_only": {"value": round(value_l, 1), "unit": "chain-steps/s (model+logL)",
                           "ms_per_step": round(dt_l / args.steps * 1e3, 4)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -36,6 +36,7 @@
 #include "tamcmc_dev.h"
 
 #define TM_WAVES (TM_THREADS / 64)
+#define TM_PDEG 8      // degree of the in-tile Taylor polynomials of the Harvey profiles
 
 // A multiplet record addressed through the CONSTANT address space: with a wave-uniform address the compiler
 // fetches it with scalar loads (s_load_dwordx8/x16) into SGPRs, which VALU instructions take directly as one
@@ -74,6 +75,15 @@ __device__ __forceinline__ double tm_exp_small(double z)
     p = __builtin_fma(p, z, 0.5);
     p = __builtin_fma(p, z, 1.0);
     p = __builtin_fma(p, z, 1.0);
+    return p;
+}
+
+// Horner evaluation of a degree-TM_PDEG polynomial whose coefficients sit in LDS (wave-uniform reads)
+__device__ __forceinline__ double tm_poly(const double *c, double z)
+{
+    double p = c[TM_PDEG];
+#pragma unroll
+    for (int j = TM_PDEG - 1; j >= 0; j--) p = __builtin_fma(p, z, c[j]);
     return p;
 }
 
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     __shared__ int s_nact;
     __shared__ int s_flags[2];
     __shared__ double s_lxc;
-    __shared__ double s_t0[TM_MAXH];
+    __shared__ double s_poly[TM_MAXH][TM_PDEG + 1];   // per Harvey profile: Taylor coefficients of u(dl) = 1/(1 + t0 e^(p dl))
+    __shared__ double s_bg[TM_PDEG + 1];              // background N0 + sum_h H_h u_h(dl) as one polynomial (likelihood-only path)
     __shared__ double s_noise[TM_NOISE_DOUBLES];
     __shared__ double s_red[2][TM_WAVES][TM_GSLOTS];   // double-buffered: one barrier per multiplet in pass 2
 
@@ -291,16 +302,51 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             nact += __popcll(mask);
         }
         if (lane == 0) s_nact = nact;
-        // per-tile Harvey constants: t0_h = (1e-3 tau x_c)^p; polynomial path valid if |p (log x - log x_c)| <= 0.04
+        // Per-tile Harvey polynomials.  With z = p (log x - log x_c), u(z) = 1/(1 + t0 e^z) is analytic inside |z| < pi
+        // (nearest pole at ln(1/t0) + i pi), so for |z| <= 0.04 its Taylor series truncated at degree 8 is exact to
+        // (0.04/pi)^9 ~ 1e-17.  Coefficients by the power-series reciprocal of D(z) = 1 + t0 sum z^j/j!.
         if (lane < 4) {
             const double span = __builtin_fmax(__builtin_fabs(lx_0 - lx_c), __builtin_fabs(lx_1 - lx_c));
             bool ok = (span == span) && (lx_c - lx_c == 0.0);
-            double t0 = 0.0;
+            double hc[TM_PDEG + 1];
+#pragma unroll
+            for (int j = 0; j <= TM_PDEG; j++) hc[j] = 0.0;
             if (lane < nh) {
-                ok = ok && (sn->p[lane] * span <= 0.04);
-                t0 = exp(sn->p[lane] * (sn->lt[lane] + lx_c));
+                const double ph = sn->p[lane];
+                ok = ok && (ph * span <= 0.04);
+                const double t0 = exp(ph * (sn->lt[lane] + lx_c));
                 ok = ok && (t0 < 1e290);
-                s_t0[lane] = t0;
+                const double ifac[TM_PDEG + 1] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320};
+                double d[TM_PDEG + 1], u[TM_PDEG + 1];
+                d[0] = 1.0 + t0;
+#pragma unroll
+                for (int j = 1; j <= TM_PDEG; j++) d[j] = t0 * ifac[j];
+                const double id0 = 1.0 / d[0];
+                u[0] = id0;
+#pragma unroll
+                for (int j = 1; j <= TM_PDEG; j++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 1; i <= j; i++) acc = __builtin_fma(d[i], u[j - i], acc);
+                    u[j] = -id0 * acc;
+                }
+                double pj = 1.0;
+                const double Hh = sn->H[lane];
+#pragma unroll
+                for (int j = 0; j <= TM_PDEG; j++) {
+                    const double cj = u[j] * pj;          // coefficient of dl^j
+                    s_poly[lane][j] = cj;
+                    hc[j] = Hh * cj;
+                    pj *= ph;
+                }
+            }
+            // background polynomial: N0 + sum over the (<= 3) profiles, combined across lanes 0..3
+#pragma unroll
+            for (int j = 0; j <= TM_PDEG; j++) {
+                double v = hc[j];
+                v += __shfl_down(v, 2, 4);
+                v += __shfl_down(v, 1, 4);
+                if (lane == 0) s_bg[j] = v + (j == 0 ? sn->N0 : 0.0);
             }
             const unsigned long long okm = __ballot(ok);
             if (lane == 0) { s_flags[0] = ((okm & 0xFull) == 0xFull) ? 1 : 0; s_lxc = lx_c; }
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     double S1 = 0.0;
     double P = 1.0;
     int esum = 0;
-    bool bad = false;
+    double Mmin = 1.0;
     double gn_[GRAD ? TM_GSLOTS : 1];   // GRAD: noise partial sums (3 per Harvey, sum w at slot 3*TM_MAXH, Gaussian at 13..15)
 #pragma unroll
     for (int s_ = 0; s_ < (GRAD ? TM_GSLOTS : 1); s_++) gn_[s_] = 0.0;
@@ -357,6 +403,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             }
         }
         double hu[TM_MAXH][GRAD ? KU : 1], harg[GRAD ? KU : 1];   // GRAD: u = 1/(1+t) per Harvey and bin (t u = 1 - u), log x per bin
+        bool n0_done = false;
         if (nh > 0) {
             double dl[KU];
 #pragma unroll
@@ -365,27 +412,23 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
 #pragma unroll
                 for (int k = 0; k < KU; k++) dl[k] -= lxc;
                 if constexpr (GRAD) {
+                    // each profile's u is needed on its own for the noise partial sums
 #pragma unroll
                     for (int h = 0; h < TM_MAXH; h++) {
                         if (h < nh) {
-                            const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
+                            const double Hh = sn->H[h];
 #pragma unroll
                             for (int k = 0; k < KU; k++) {
-                                const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
-                                hu[h][k] = tm_rcp(t + 1.0);
+                                hu[h][k] = tm_poly(s_poly[h], dl[k]);
                                 acc[k] = __builtin_fma(Hh, hu[h][k], acc[k]);
                             }
                         }
                     }
                 } else {
-                    for (int h = 0; h < nh; h++) {
-                        const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
+                    // whole background (all profiles + white noise) as ONE polynomial: 8 FMAs per bin
 #pragma unroll
-                        for (int k = 0; k < KU; k++) {
-                            const double t = t0 * tm_exp_small(ph * dl[k]);
-                            acc[k] = __builtin_fma(Hh, tm_rcp(t + 1.0), acc[k]);
-                        }
-                    }
+                    for (int k = 0; k < KU; k++) acc[k] += tm_poly(s_bg, dl[k]);
+                    n0_done = true;
                 }
             } else {
 #pragma unroll
@@ -411,8 +454,10 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 acc[k] = gA * exp((-0.5 * (dd * dd)) / gs2) + acc[k];
             }
         }
+        if (!n0_done) {
 #pragma unroll
-        for (int k = 0; k < KU; k++) acc[k] += N0;
+            for (int k = 0; k < KU; k++) acc[k] += N0;
+        }
 
         if (row >= 0) {
 #pragma unroll
@@ -426,14 +471,16 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             for (int k = 0; k < KU; k++) {
                 double wv = 0.0;
                 if (bi[k] >= 0) {
+                    // A model value that is NaN, +-inf or 0 turns rM (and so S1) into NaN by itself (v_rcp_f64 + the
+                    // Newton steps); a negative one is caught by the running minimum.  Either way logL becomes NaN,
+                    // which is what log() of such a value gives the reference.
                     const double M = acc[k];
                     const double yv = a.y[bi[k]];
-                    const bool ok = (M > 0.0) && (M < 1.7e308);
-                    bad = bad || !ok;
-                    const double rM = tm_rcp(ok ? M : 1.0);
+                    Mmin = __builtin_fmin(Mmin, M);
+                    const double rM = tm_rcp(M);
                     S1 = __builtin_fma(yv, rM, S1);
                     int e;
-                    P *= frexp(ok ? M : 1.0, &e);
+                    P *= frexp(M, &e);
                     esum += e;
                     wv = wscale * (yv * rM * rM - rM);   // d(logL/T)/dM_i
                 }
@@ -490,7 +537,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     double S2 = 0.0;
     if (a.likelihood_case == 0) {
         S2 = log(P) + (double)esum * 0.693147180559945309417232;
-        if (bad) S2 = __builtin_nan("");
+        if (!(Mmin > 0.0)) S2 = __builtin_nan("");
     }
     S1 = tm_wave_sum(S1);
     S2 = tm_wave_sum(S2);
