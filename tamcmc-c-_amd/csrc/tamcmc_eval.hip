@@ -153,6 +153,24 @@ __device__ __forceinline__ double tm_mult_value(double x2, const double (&nu2)[N
     return s;
 }
 
+// Forward only: the same sum as one rational N/Q built term by term (N <- N E_m + h_m Q, Q <- Q E_m: 3 ops per
+// component instead of the 4 of batch inversion, whose individual 1/E_m only the gradient needs).
+template <int NC>
+__device__ __forceinline__ double tm_mult_sum(double x2, const double (&nu2)[NC], const double (&hq)[NC], double g2)
+{
+    double d = x2 - nu2[0];
+    double Q = __builtin_fma(d, d, g2);
+    double N = hq[0];
+#pragma unroll
+    for (int m = 1; m < NC; m++) {
+        d = x2 - nu2[m];
+        const double E = __builtin_fma(d, d, g2);
+        N = __builtin_fma(hq[m], Q, N * E);
+        Q = Q * E;
+    }
+    return N * tm_rcp(Q);
+}
+
 // Forward: add multiplet `sm` (LDS) to acc[] for KU bins.
 template <int NC, int KU, bool ASYM>
 __device__ __forceinline__ void tm_accum_mult(TmMultK sm, const double (&x2)[KU], const int (&bi)[KU], double (&acc)[KU])
@@ -165,8 +183,7 @@ __device__ __forceinline__ void tm_accum_mult(TmMultK sm, const double (&x2)[KU]
     const double aAh = ASYM ? 0.5 * sm->aA : 0.0, aB = ASYM ? sm->aB : 1.0, c2 = ASYM ? sm->c2 : 0.0;
 #pragma unroll
     for (int k = 0; k < KU; k++) {
-        double d[NC], r[NC];
-        double s = tm_mult_value<NC>(x2[k], nu2, hq, g2, d, r);
+        double s = tm_mult_sum<NC>(x2[k], nu2, hq, g2);
         if (ASYM) {
             const double a = __builtin_fma(x2[k], aAh, aB);
             s = s * __builtin_fma(a, a, c2);
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     __shared__ int s_nact;
     __shared__ int s_flags[2];
     __shared__ double s_lxc;
-    __shared__ double s_poly[TM_MAXH][TM_PDEG + 1];   // per Harvey profile: Taylor coefficients of u(dl) = 1/(1 + t0 e^(p dl))
+    __shared__ double s_t0[TM_MAXH];                  // per Harvey profile: t at the tile centre (gradient path)
     __shared__ double s_bg[TM_PDEG + 1];              // background N0 + sum_h H_h u_h(dl) as one polynomial (likelihood-only path)
     __shared__ double s_noise[TM_NOISE_DOUBLES];
     __shared__ double s_red[2][TM_WAVES][TM_GSLOTS];   // double-buffered: one barrier per multiplet in pass 2
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 ok = ok && (ph * span <= 0.04);
                 const double t0 = exp(ph * (sn->lt[lane] + lx_c));
                 ok = ok && (t0 < 1e290);
+                s_t0[lane] = t0;
                 const double ifac[TM_PDEG + 1] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320};
                 double d[TM_PDEG + 1], u[TM_PDEG + 1];
                 d[0] = 1.0 + t0;
@@ -334,9 +352,8 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 const double Hh = sn->H[lane];
 #pragma unroll
                 for (int j = 0; j <= TM_PDEG; j++) {
-                    const double cj = u[j] * pj;          // coefficient of dl^j
-                    s_poly[lane][j] = cj;
-                    hc[j] = Hh * cj;
+                    hc[j] = Hh * (u[j] * pj);             // coefficient of dl^j
+
                     pj *= ph;
                 }
             }
@@ -416,10 +433,11 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
 #pragma unroll
                     for (int h = 0; h < TM_MAXH; h++) {
                         if (h < nh) {
-                            const double Hh = sn->H[h];
+                            const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
 #pragma unroll
                             for (int k = 0; k < KU; k++) {
-                                hu[h][k] = tm_poly(s_poly[h], dl[k]);
+                                const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
+                                hu[h][k] = tm_rcp(t + 1.0);
                                 acc[k] = __builtin_fma(Hh, hu[h][k], acc[k]);
                             }
                         }
