@@ -48,6 +48,8 @@ struct tamcmc_ctx {
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
     void *d_chain_rec = nullptr, *d_aux = nullptr;   // TmChain / TmMultFull records kept for the backward kernel
+    TmTileRec *d_trec = nullptr;   // [cap][tiles_max] tile descriptors
+    int32_t *d_tidx = nullptr;     // [cap][tiles_max][n_mult] active multiplet lists
     double *d_model = nullptr;
     size_t model_cap = 0;
     // variables
@@ -146,6 +148,7 @@ static void free_batch(tamcmc_ctx *c)
     (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad);
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
+    (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
     c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = nullptr;
     c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
     c->cap = 0; c->cap_grad = false;
@@ -168,6 +171,8 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMalloc(&c->d_rows, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_mult, n * nm * sizeof(TmMult)));
     TM_HIP(hipMalloc(&c->d_noise, n * sizeof(TmNoise)));
+    TM_HIP(hipMalloc(&c->d_trec, n * c->tiles_max * sizeof(TmTileRec)));
+    TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(int32_t)));
     if (g) {
         TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g * nm * TM_GSLOTS * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g * TM_NSLOTS * sizeof(double)));
@@ -342,12 +347,12 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int K = grad ? c->Kg : c->K;
     const int S = grad ? c->Sg : c->S;
     const int tiles = grad ? c->tiles_g : c->tiles;
-    int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_mult, c->d_noise, grad ? c->d_chain_rec : nullptr,
-                             grad ? c->d_aux : nullptr, c->stream);
+    int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_lx, TM_THREADS * K * S, tiles, c->d_mult, c->d_noise, c->d_trec,
+                             c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
-    a.mult = c->d_mult; a.noise = c->d_noise; a.Tcoefs = d_T;
+    a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.Tcoefs = d_T;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
     a.row_of_chain = d_rows; a.model_out = d_model;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;

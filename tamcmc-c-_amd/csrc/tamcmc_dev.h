@@ -17,6 +17,7 @@
 #define TM_MAXMULT 256 // multiplets per chain (Nmax*(lmax+1) or sum Nfl); staged in LDS, 160 B each
 #define TM_GSLOTS 24   // gradient partials per (tile, multiplet): 3 per component + 3 asymmetry sums
 #define TM_NSLOTS 16   // gradient partials per tile for the noise terms: 3 per Harvey + N0 (+pad)
+#define TM_PDEG 8      // degree of the in-tile Taylor polynomials of the Harvey profiles
 
 // model families (how the params row is unpacked)
 #define TM_FAM_GAUSS  0  // ids 0, 1          models.cpp:1968-2034
@@ -69,10 +70,23 @@ struct TmNoise {
 static_assert(sizeof(TmNoise) == 120, "TmNoise layout");
 #define TM_NOISE_DOUBLES 15
 
+// Per (chain, tile) descriptor written by the setup kernel and read by the eval kernel through scalar loads:
+// everything a tile needs besides the multiplet records themselves.
+struct TmTileRec {
+    double bg[TM_PDEG + 1];   // background N0 + sum_h H_h/(1 + t_h) as a polynomial in (log x - lxc)
+    double t0[TM_MAXH];       // t_h = (1e-3 tau_h x_c)^p_h at the tile centre
+    double lxc;               // log x at the tile centre
+    int32_t npoly;            // 1: polynomials valid on this tile (|p_h (log x - lxc)| <= 0.04, t0 finite), 0: use exp
+    int32_t nact;             // multiplets whose window meets the tile; their indices are tidx[0..nact)
+};
+static_assert(sizeof(TmTileRec) == 8 * (TM_PDEG + 1 + TM_MAXH + 2), "TmTileRec layout");
+
 struct TmEvalArgs {
     const double *x, *y, *lx, *isig2;
     const TmMult *mult;
     const TmNoise *noise;
+    const TmTileRec *trec;      // [Nchains][tiles]
+    const int32_t *tidx;        // [Nchains][tiles][n_mult] active multiplet indices, table order
     const double *Tcoefs;
     double *part;               // [Nchains][tiles][2]
     double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL
@@ -88,7 +102,9 @@ struct TmEvalArgs {
 extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, TmMult *d_mult, TmNoise *d_noise,
+// bins_per_tile / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_lx, int bins_per_tile,
+                    int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
                     void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();

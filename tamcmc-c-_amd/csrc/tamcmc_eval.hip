@@ -36,13 +36,15 @@
 #include "tamcmc_dev.h"
 
 #define TM_WAVES (TM_THREADS / 64)
-#define TM_PDEG 8      // degree of the in-tile Taylor polynomials of the Harvey profiles
 
 // A multiplet record addressed through the CONSTANT address space: with a wave-uniform address the compiler
 // fetches it with scalar loads (s_load_dwordx8/x16) into SGPRs, which VALU instructions take directly as one
 // operand -- no LDS read, no VGPRs for the record.  The table was written by the previous kernel (setup), so
 // it is invariant for this launch.
 typedef const __attribute__((address_space(4))) TmMult *TmMultK;
+typedef const __attribute__((address_space(4))) TmTileRec *TmTileRecK;
+typedef const __attribute__((address_space(4))) TmNoise *TmNoiseK;
+typedef const __attribute__((address_space(4))) int32_t *TmIdxK;
 
 // 1/x for finite, normal, positive x: v_rcp_f64 + two Newton steps (no scaling / fix-up needed
 // because every denominator here is bounded away from the subnormal and overflow ranges).
@@ -78,12 +80,12 @@ __device__ __forceinline__ double tm_exp_small(double z)
     return p;
 }
 
-// Horner evaluation of a degree-TM_PDEG polynomial whose coefficients sit in LDS (wave-uniform reads)
-__device__ __forceinline__ double tm_poly(const double *c, double z)
+// Horner evaluation of the tile's background polynomial; the coefficients are SGPR operands (scalar loads)
+__device__ __forceinline__ double tm_poly(TmTileRecK tr, double z)
 {
-    double p = c[TM_PDEG];
+    double p = tr->bg[TM_PDEG];
 #pragma unroll
-    for (int j = TM_PDEG - 1; j >= 0; j--) p = __builtin_fma(p, z, c[j]);
+    for (int j = TM_PDEG - 1; j >= 0; j--) p = __builtin_fma(p, z, tr->bg[j]);
     return p;
 }
 
@@ -277,102 +279,21 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     const int base = tile * TB;
 
     extern __shared__ double s_dyn[];
-    double *s_mult = s_dyn;                                          // [n_mult * TM_MULT_DOUBLES]
-    double *s_w = s_dyn + (size_t)a.n_mult * TM_MULT_DOUBLES;        // [TM_THREADS * KU * S]   (GRAD)
-    __shared__ int s_idx[TM_MAXMULT];
-    __shared__ int s_nact;
-    __shared__ int s_flags[2];
-    __shared__ double s_lxc;
-    __shared__ double s_t0[TM_MAXH];                  // per Harvey profile: t at the tile centre (gradient path)
-    __shared__ double s_bg[TM_PDEG + 1];              // background N0 + sum_h H_h u_h(dl) as one polynomial (likelihood-only path)
-    __shared__ double s_noise[TM_NOISE_DOUBLES];
+    double *s_w = s_dyn;                                             // [TM_THREADS * KU * S]   (GRAD only)
     __shared__ double s_red[2][TM_WAVES][TM_GSLOTS];   // double-buffered: one barrier per multiplet in pass 2
 
-    const TmMult *gm = a.mult + (size_t)chain * a.n_mult;
-    const TmNoise *gn = a.noise + chain;
-
-    // ---------------- prologue: one global round trip ----------------
-    // The chain's whole multiplet table (160 B each) and noise record go to LDS with coalesced loads;
-    // the list of multiplets whose window meets this tile is then built from LDS (ballot, table order).
-    for (int e = tid; e < a.n_mult * TM_MULT_DOUBLES; e += TM_THREADS) s_mult[e] = reinterpret_cast<const double *>(gm)[e];
-    if (tid < TM_NOISE_DOUBLES) s_noise[tid] = reinterpret_cast<const double *>(gn)[tid];
-    double lx_c = 0.0, lx_0 = 0.0, lx_1 = 0.0;
-    if (tid < 4) {
-        int ic = base + TB / 2; if (ic > a.Nx - 1) ic = a.Nx - 1;
-        int i1 = base + TB - 1; if (i1 > a.Nx - 1) i1 = a.Nx - 1;
-        lx_c = a.lx[ic]; lx_0 = a.lx[base]; lx_1 = a.lx[i1];
-    }
-    __syncthreads();
-    const TmNoise *sn = reinterpret_cast<const TmNoise *>(s_noise);
+    // ---------------- prologue: nothing but scalar loads ----------------
+    // Everything a tile needs -- its list of active multiplets (table order), the background polynomial, the
+    // chain's noise record, the multiplet records themselves -- was prepared by the setup kernel and is
+    // wave-uniform: it is fetched with s_load into SGPRs.  No LDS staging, no barrier before the first bin.
+    const TmMult *__restrict__ gm = a.mult + (size_t)chain * a.n_mult;
+    TmTileRecK tr = (TmTileRecK)(a.trec + (size_t)chain * a.tiles + tile);
+    TmNoiseK sn = (TmNoiseK)(a.noise + chain);
+    TmIdxK tix = (TmIdxK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
     const int nh = sn->nh;
-    if (wave == 0) {
-        int nact = 0;
-        for (int c0 = 0; c0 < a.n_mult; c0 += 64) {
-            const int j = c0 + lane;
-            bool act = false;
-            if (j < a.n_mult) {
-                const TmMult *m = reinterpret_cast<const TmMult *>(s_mult) + j;
-                act = (m->imin < base + TB) && (m->imax > base);
-            }
-            const unsigned long long mask = __ballot(act);
-            if (act) s_idx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = j;
-            nact += __popcll(mask);
-        }
-        if (lane == 0) s_nact = nact;
-        // Per-tile Harvey polynomials.  With z = p (log x - log x_c), u(z) = 1/(1 + t0 e^z) is analytic inside |z| < pi
-        // (nearest pole at ln(1/t0) + i pi), so for |z| <= 0.04 its Taylor series truncated at degree 8 is exact to
-        // (0.04/pi)^9 ~ 1e-17.  Coefficients by the power-series reciprocal of D(z) = 1 + t0 sum z^j/j!.
-        if (lane < 4) {
-            const double span = __builtin_fmax(__builtin_fabs(lx_0 - lx_c), __builtin_fabs(lx_1 - lx_c));
-            bool ok = (span == span) && (lx_c - lx_c == 0.0);
-            double hc[TM_PDEG + 1];
-#pragma unroll
-            for (int j = 0; j <= TM_PDEG; j++) hc[j] = 0.0;
-            if (lane < nh) {
-                const double ph = sn->p[lane];
-                ok = ok && (ph * span <= 0.04);
-                const double t0 = exp(ph * (sn->lt[lane] + lx_c));
-                ok = ok && (t0 < 1e290);
-                s_t0[lane] = t0;
-                const double ifac[TM_PDEG + 1] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320};
-                double d[TM_PDEG + 1], u[TM_PDEG + 1];
-                d[0] = 1.0 + t0;
-#pragma unroll
-                for (int j = 1; j <= TM_PDEG; j++) d[j] = t0 * ifac[j];
-                const double id0 = 1.0 / d[0];
-                u[0] = id0;
-#pragma unroll
-                for (int j = 1; j <= TM_PDEG; j++) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i = 1; i <= j; i++) acc = __builtin_fma(d[i], u[j - i], acc);
-                    u[j] = -id0 * acc;
-                }
-                double pj = 1.0;
-                const double Hh = sn->H[lane];
-#pragma unroll
-                for (int j = 0; j <= TM_PDEG; j++) {
-                    hc[j] = Hh * (u[j] * pj);             // coefficient of dl^j
-
-                    pj *= ph;
-                }
-            }
-            // background polynomial: N0 + sum over the (<= 3) profiles, combined across lanes 0..3
-#pragma unroll
-            for (int j = 0; j <= TM_PDEG; j++) {
-                double v = hc[j];
-                v += __shfl_down(v, 2, 4);
-                v += __shfl_down(v, 1, 4);
-                if (lane == 0) s_bg[j] = v + (j == 0 ? sn->N0 : 0.0);
-            }
-            const unsigned long long okm = __ballot(ok);
-            if (lane == 0) { s_flags[0] = ((okm & 0xFull) == 0xFull) ? 1 : 0; s_lxc = lx_c; }
-        }
-    }
-    __syncthreads();
-    const int nact = s_nact;
-    const bool npoly = s_flags[0] != 0;
-    const double lxc = s_lxc;
+    const int nact = tr->nact;
+    const bool npoly = tr->npoly != 0;
+    const double lxc = tr->lxc;
     const bool has_gauss = sn->has_gauss != 0;
     const double N0 = sn->N0;
     const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
@@ -400,7 +321,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             acc[k] = 0.0;
         }
         for (int jj = 0; jj < nact; jj++) {
-            TmMultK sm = (TmMultK)(gm + __builtin_amdgcn_readfirstlane(s_idx[jj]));
+            TmMultK sm = (TmMultK)(gm + tix[jj]);
             const int lo = base + u * KU * TM_THREADS;
             if (lo + KU * TM_THREADS <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
             if (sm->has_asym) {
@@ -433,7 +354,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
 #pragma unroll
                     for (int h = 0; h < TM_MAXH; h++) {
                         if (h < nh) {
-                            const double Hh = sn->H[h], ph = sn->p[h], t0 = s_t0[h];
+                            const double Hh = sn->H[h], ph = sn->p[h], t0 = tr->t0[h];
 #pragma unroll
                             for (int k = 0; k < KU; k++) {
                                 const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
@@ -445,7 +366,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 } else {
                     // whole background (all profiles + white noise) as ONE polynomial: 8 FMAs per bin
 #pragma unroll
-                    for (int k = 0; k < KU; k++) acc[k] += tm_poly(s_bg, dl[k]);
+                    for (int k = 0; k < KU; k++) acc[k] += tm_poly(tr, dl[k]);
                     n0_done = true;
                 }
             } else {
@@ -595,7 +516,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
 #else
         for (int jj = 0; jj < nact; jj++) {
 #endif
-            TmMultK sm = (TmMultK)(gm + __builtin_amdgcn_readfirstlane(s_idx[jj]));
+            TmMultK sm = (TmMultK)(gm + tix[jj]);
             const int nc = sm->ncomp;
             double *red = s_red[(jj + 1) & 1][wave];
             if (sm->has_asym) {
@@ -621,7 +542,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
 #pragma unroll
                     for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[(jj + 1) & 1][wv][tid];
                 }
-                a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + s_idx[jj]) * TM_GSLOTS + tid] = t;
+                a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + tix[jj]) * TM_GSLOTS + tid] = t;
             }
         }
     }
@@ -658,9 +579,7 @@ template <int KU>
 static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
 {
     dim3 grid(a.tiles, Nchains), block(TM_THREADS);
-    size_t lds = (size_t)a.n_mult * TM_MULT_DOUBLES * sizeof(double);
-    if (grad) lds += (size_t)TM_THREADS * KU * a.S * sizeof(double);
-    if (lds == 0) lds = 8;
+    size_t lds = grad ? (size_t)TM_THREADS * KU * a.S * sizeof(double) : 8;
     if (lds > 48 * 1024) {
         const void *fn = grad ? reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, true>)
                               : reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, false>);
