@@ -48,6 +48,7 @@ struct tamcmc_ctx {
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
     void *d_chain_rec = nullptr, *d_aux = nullptr;   // TmChain / TmMultFull records kept for the backward kernel
+    int32_t *d_ticket = nullptr;   // [cap] arrival counters of the in-launch finalize (kept at zero between launches)
     TmTileRec *d_trec = nullptr;   // [cap][tiles_max] tile descriptors
     int32_t *d_tidx = nullptr;     // [cap][tiles_max][n_mult] active multiplet lists
     double *d_model = nullptr;
@@ -149,6 +150,7 @@ static void free_batch(tamcmc_ctx *c)
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
     (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
+    (void)hipFree(c->d_ticket); c->d_ticket = nullptr;
     c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = nullptr;
     c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
     c->cap = 0; c->cap_grad = false;
@@ -171,6 +173,8 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMalloc(&c->d_rows, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_mult, n * nm * sizeof(TmMult)));
     TM_HIP(hipMalloc(&c->d_noise, n * sizeof(TmNoise)));
+    TM_HIP(hipMalloc(&c->d_ticket, n * sizeof(int32_t)));
+    TM_HIP(hipMemset(c->d_ticket, 0, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_trec, n * c->tiles_max * sizeof(TmTileRec)));
     TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(int32_t)));
     if (g) {
@@ -355,6 +359,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.Tcoefs = d_T;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
     a.row_of_chain = d_rows; a.model_out = d_model;
+    a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
     a.S = S;
@@ -373,8 +378,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
         c->ev_used += 2;
     }
     if (!grad) {
-        rc = tm_launch_finalize(c->L, Nchains, tiles, c->d_part, c->d_noise, d_T, d_logL, d_status, c->stream);
-        if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "finalize launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+        // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
         rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, d_T, c->d_chain_rec, c->d_aux,
                                 c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->Nvars, c->d_relax, d_grad, d_logL,

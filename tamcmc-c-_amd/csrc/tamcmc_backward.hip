@@ -88,7 +88,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         for (int t = 0; t < tiles; t++) acc += gnoise[((size_t)chain * tiles + t) * TM_NSLOTS + sl];
         s_gn[sl] = acc;
     }
-    // finalize (same arithmetic and order as tamcmc_finalize_kernel): wave 3
+    // finalize (same arithmetic and order as the likelihood-only path's in-launch finalize): wave 3
     if (tid >= 192) {
         const int lane = tid - 192;
         const double *pp = part + (size_t)chain * tiles * 2;

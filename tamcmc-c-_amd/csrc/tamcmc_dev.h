@@ -91,6 +91,9 @@ struct TmEvalArgs {
     double *part;               // [Nchains][tiles][2]
     double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL
     double *gnoise;             // [Nchains][tiles][TM_NSLOTS] or NULL
+    int32_t *ticket;            // [Nchains] arrival counters (zero between launches) for the in-launch finalize, or NULL
+    double *logL;               // [Nchains] outputs of the in-launch finalize (likelihood-only path)
+    int32_t *status;
     const int32_t *row_of_chain;// NULL or [Nchains]: row of model_out to fill, -1 none
     double *model_out;
     int32_t Nx, n_mult, tiles, likelihood_case;
@@ -109,8 +112,6 @@ int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, cons
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
-int tm_launch_finalize(const TmLayout &L, int Nchains, int tiles, const double *d_part, const TmNoise *d_noise,
-                       const double *d_Tcoefs, double *d_logL, int32_t *d_status, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
 int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,

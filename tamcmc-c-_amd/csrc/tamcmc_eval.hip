@@ -30,8 +30,9 @@
 //   thread and tile instead of one per bin.
 //   Reductions: likelihood: wave shuffles -> one LDS slot per wave -> one partial per (chain, tile);
 //   gradient: a transposing butterfly (V values per lane cost ~V exchanges, not 6V) -> LDS -> one
-//   partial per (chain, tile, multiplet, slot).  The sums over tiles run in a fixed order in
-//   tamcmc_finalize_kernel / tamcmc_backward_kernel (no atomics anywhere: bitwise reproducible).
+//   partial per (chain, tile, multiplet, slot).  The sums over tiles run in a fixed order (last-arriving
+//   workgroup of the chain, or tamcmc_backward_kernel on the gradient path); the only atomic is an arrival
+//   counter, never a floating-point accumulation: results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
 
@@ -482,13 +483,53 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     S2 = tm_wave_sum(S2);
     if (lane == 0) { s_red[0][wave][0] = S1; s_red[0][wave][1] = S2; }
     __syncthreads();
-    if (tid == 0) {
-        double t1 = 0.0, t2 = 0.0;
+    if constexpr (GRAD) {
+        if (tid == 0) {
+            double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
-        double *out = a.part + ((size_t)chain * a.tiles + tile) * 2;
-        out[0] = t1;
-        out[1] = t2;
+            for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
+            double *out = a.part + ((size_t)chain * a.tiles + tile) * 2;   // summed by the backward kernel
+            out[0] = t1;
+            out[1] = t2;
+        }
+    } else if (wave == 0) {
+        // Finalize inside this launch: the workgroup that publishes the LAST tile partial of a chain sums all of them
+        // in a fixed order (lane-strided, then a wave tree), so the result does not depend on which workgroup that is.
+        // Hand-off without cache-wide fences: the partials are written and read with agent-scope relaxed atomics
+        // (8-byte write-through stores / L1-bypassing loads), the publisher drains its stores (vmcnt(0)) before it
+        // takes its ticket, and the last arriver reads only after its ticket returned -- placement-independent.
+        int last = 0;
+        double *pp = a.part + (size_t)chain * a.tiles * 2;
+        if (lane == 0) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
+            __hip_atomic_store(pp + 2 * tile, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 2 * tile + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int prev = __hip_atomic_fetch_add(a.ticket + chain, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev == a.tiles - 1) ? 1 : 0;
+        }
+        last = __shfl(last, 0, 64);
+        if (last) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int t = lane; t < a.tiles; t += 64) {
+                s1 += __hip_atomic_load(pp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(pp + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s1 = tm_wave_sum(s1);
+            s2 = tm_wave_sum(s2);
+            if (lane == 0) {
+                double f = (a.likelihood_case == 0) ? -a.like_p * (s1 + s2) : -s1;
+                f = f / a.Tcoefs[chain];
+                int st = a.noise[chain].status;
+                if (st != 0) f = __builtin_nan("");
+                else if (!(f == f)) st = 1;
+                a.logL[chain] = f;
+                if (a.status) a.status[chain] = st;
+                __hip_atomic_store(a.ticket + chain, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+        }
     }
 
     // ---------------- pass 2: gradient partial sums ----------------
@@ -548,33 +589,6 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     }
 }
 
-// Sum the per-tile partials of each chain in a fixed order and apply -p (...) / T.
-// model_def.cpp:300-302 (logL / Tcoefs[m]); NaN -> status 1; empty window -> NaN, status 2.
-__global__ __launch_bounds__(64) void tamcmc_finalize_kernel(int tiles, int likelihood_case, double like_p,
-                                                             const double *__restrict__ part,
-                                                             const TmNoise *__restrict__ noise,
-                                                             const double *__restrict__ Tcoefs,
-                                                             double *__restrict__ logL, int32_t *__restrict__ status)
-{
-    const int chain = blockIdx.x, lane = threadIdx.x;
-    const double *p = part + (size_t)chain * tiles * 2;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = lane; t < tiles; t += 64) { s1 += p[2 * t]; s2 += p[2 * t + 1]; }
-    s1 = tm_wave_sum(s1);
-    s2 = tm_wave_sum(s2);
-    if (lane == 0) {
-        double f;
-        if (likelihood_case == 0) f = -like_p * (s1 + s2);
-        else                      f = -s1;
-        f = f / Tcoefs[chain];
-        int st = noise[chain].status;
-        if (st != 0) f = __builtin_nan("");
-        else if (!(f == f)) st = 1;
-        logL[chain] = f;
-        if (status) status[chain] = st;
-    }
-}
-
 template <int KU>
 static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
 {
@@ -600,12 +614,4 @@ int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *st
     case 4: return tm_launch_eval_k<4>(a, Nchains, grad, (hipStream_t)stream);
     default: return (int)hipErrorInvalidValue;
     }
-}
-
-int tm_launch_finalize(const TmLayout &L, int Nchains, int tiles, const double *d_part, const TmNoise *d_noise,
-                       const double *d_Tcoefs, double *d_logL, int32_t *d_status, void *stream)
-{
-    hipLaunchKernelGGL(tamcmc_finalize_kernel, dim3(Nchains), dim3(64), 0, (hipStream_t)stream, tiles,
-                       L.likelihood_case, L.like_p, d_part, d_noise, d_Tcoefs, d_logL, d_status);
-    return (int)hipGetLastError();
 }

@@ -68,6 +68,62 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         const double n0 = p[z + Nnoise - 1];
         N.N0 = (take_abs ? fabs(n0) : n0) + extra;
     }
+    if (tid >= 64) {
+        // Wave 1, concurrently with wave 0's multiplet derivation: the Harvey background of every tile as Taylor
+        // polynomials in z = p (log x - log x_c).  u(z) = 1/(1 + t0 e^z) is analytic for |z| < pi (nearest pole at
+        // ln(1/t0) + i pi), so for |z| <= 0.04 the series truncated at degree 8 is exact to (0.04/pi)^9 ~ 1e-17.
+        // Coefficients by the power-series reciprocal of D(z) = 1 + t0 sum z^j/j!.
+        // s_N was written by lane 0 of THIS wave: LDS operations of one wave complete in order.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int tile = tid - 64; tile < tiles; tile += 64) {
+            const int base = tile * TB;
+            TmTileRec R;
+            R.nact = 0;
+            int ic = base + TB / 2; if (ic > L.Nx - 1) ic = L.Nx - 1;
+            int i1 = base + TB - 1; if (i1 > L.Nx - 1) i1 = L.Nx - 1;
+            const double lx_c = lx[ic], lx_0 = lx[base], lx_1 = lx[i1];
+            const double span = fmax(fabs(lx_0 - lx_c), fabs(lx_1 - lx_c));
+            bool ok = (span == span) && (lx_c - lx_c == 0.0);
+            R.lxc = lx_c;
+#pragma unroll
+            for (int j = 0; j <= TM_PDEG; j++) R.bg[j] = 0.0;
+            R.bg[0] = s_N.N0;
+#pragma unroll
+            for (int h = 0; h < TM_MAXH; h++) {
+                R.t0[h] = 0.0;
+                if (h < s_N.nh) {
+                    const double ph = s_N.p[h], Hh = s_N.H[h];
+                    ok = ok && (ph * span <= 0.04);
+                    const double t0 = exp(ph * (s_N.lt[h] + lx_c));
+                    ok = ok && (t0 < 1e290);
+                    R.t0[h] = t0;
+                    const double ifac[TM_PDEG + 1] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320};
+                    double d[TM_PDEG + 1], u[TM_PDEG + 1];
+                    d[0] = 1.0 + t0;
+#pragma unroll
+                    for (int j = 1; j <= TM_PDEG; j++) d[j] = t0 * ifac[j];
+                    const double id0 = 1.0 / d[0];
+                    u[0] = id0;
+#pragma unroll
+                    for (int j = 1; j <= TM_PDEG; j++) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int i = 1; i <= j; i++) acc = acc + d[i] * u[j - i];
+                        u[j] = -id0 * acc;
+                    }
+                    double pj = 1.0;
+#pragma unroll
+                    for (int j = 0; j <= TM_PDEG; j++) {
+                        R.bg[j] = R.bg[j] + Hh * (u[j] * pj);   // coefficient of (log x - lxc)^j
+                        pj = pj * ph;
+                    }
+                }
+            }
+            R.npoly = ok ? 1 : 0;
+            trec[(size_t)chain * tiles + tile] = R;    // nact is filled in below, once the windows are known
+        }
+    }
 
     if (L.family != TM_FAM_GAUSS && tid < 64) {
         for (int j = tid; j < L.n_mult; j += 64) {
@@ -103,11 +159,8 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         noise[chain] = s_N;
     }
 
-    // ---------------- tile descriptors: one thread per tile ----------------
-    // (a) the multiplets whose window meets the tile, in table order (fixes the summation order of the eval kernel);
-    // (b) the Harvey background of the tile as Taylor polynomials in z = p (log x - log x_c): u(z) = 1/(1 + t0 e^z) is
-    //     analytic for |z| < pi (nearest pole at ln(1/t0) + i pi), so for |z| <= 0.04 the series truncated at degree 8
-    //     is exact to (0.04/pi)^9 ~ 1e-17.  Coefficients by the power-series reciprocal of D(z) = 1 + t0 sum z^j/j!.
+    // ---------------- active multiplet lists: one thread per tile ----------------
+    // the multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel)
     const int nm = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
     for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) {
         const int base = tile * TB;
@@ -115,53 +168,9 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         int nact = 0;
         for (int j = 0; j < nm; j++)
             if (s_win[j][0] < base + TB && s_win[j][1] > base) ti[nact++] = j;
-        TmTileRec R;
-        R.nact = nact;
-        int ic = base + TB / 2; if (ic > L.Nx - 1) ic = L.Nx - 1;
-        int i1 = base + TB - 1; if (i1 > L.Nx - 1) i1 = L.Nx - 1;
-        const double lx_c = lx[ic], lx_0 = lx[base], lx_1 = lx[i1];
-        const double span = fmax(fabs(lx_0 - lx_c), fabs(lx_1 - lx_c));
-        bool ok = (span == span) && (lx_c - lx_c == 0.0);
-        R.lxc = lx_c;
-#pragma unroll
-        for (int j = 0; j <= TM_PDEG; j++) R.bg[j] = 0.0;
-        R.bg[0] = s_N.N0;
-#pragma unroll
-        for (int h = 0; h < TM_MAXH; h++) {
-            R.t0[h] = 0.0;
-            if (h < s_N.nh) {
-                const double ph = s_N.p[h], Hh = s_N.H[h];
-                ok = ok && (ph * span <= 0.04);
-                const double t0 = exp(ph * (s_N.lt[h] + lx_c));
-                ok = ok && (t0 < 1e290);
-                R.t0[h] = t0;
-                const double ifac[TM_PDEG + 1] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320};
-                double d[TM_PDEG + 1], u[TM_PDEG + 1];
-                d[0] = 1.0 + t0;
-#pragma unroll
-                for (int j = 1; j <= TM_PDEG; j++) d[j] = t0 * ifac[j];
-                const double id0 = 1.0 / d[0];
-                u[0] = id0;
-#pragma unroll
-                for (int j = 1; j <= TM_PDEG; j++) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i = 1; i <= j; i++) acc = acc + d[i] * u[j - i];
-                    u[j] = -id0 * acc;
-                }
-                double pj = 1.0;
-#pragma unroll
-                for (int j = 0; j <= TM_PDEG; j++) {
-                    R.bg[j] = R.bg[j] + Hh * (u[j] * pj);   // coefficient of (log x - lxc)^j
-                    pj = pj * ph;
-                }
-            }
-        }
-        R.npoly = ok ? 1 : 0;
-        trec[(size_t)chain * tiles + tile] = R;
+        trec[(size_t)chain * tiles + tile].nact = nact;
     }
 }
-
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_lx, int bins_per_tile,
                     int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
