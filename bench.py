@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--nx", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -52,8 +54,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.single_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -89,7 +96,8 @@ def main():
 
     def timed(n, grad):
         # barrier + synchronize on both sides, exactly n steps, MAX over ranks (tests/test_shard_gloo.py)
-        return shard.timed_loop(lambda: step(grad), n, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
+        return shard.timed_loop(lambda: step(grad), n, lambda: torch.cuda.synchronize(dev), dist=dist,
+                                device=dev if args.backend == "nccl" else None)
 
     for _ in range(args.warmup):
         step(True)
@@ -133,9 +141,9 @@ def main():
                 return insts * scale * 4.0 / (t_s * simds * ghz * 1e9)
             valu = {"source": "profiles/hbm_traffic.json (rocprofv3 SQ_INSTS_VALU, GRBM_GUI_ACTIVE clock estimate)",
                     "grad_kernel_issue_frac": round(busy(pm["eval_grad_valu_insts_per_launch"], k_avg_s,
-                                                         clk.get("tamcmc_eval_kernel<4, true>", 2.4)), 3),
+                                                         clk.get("grad") or 2.4), 3),
                     "logL_kernel_issue_frac": round(busy(pm["eval_logL_valu_insts_per_launch"], kl_avg_s,
-                                                         clk.get("tamcmc_eval_kernel<4, false>", 2.4)), 3)}
+                                                         clk.get("logL") or 2.4), 3)}
         except Exception:
             traffic, traffic_l, valu = None, None, None
     roofline = {
@@ -149,6 +157,23 @@ def main():
                       "frac": round(bytes_per_launch / kl_avg_s / 1e9 / HBM_PEAK_GBS, 5),
                       "kernel_ms": round(kl_avg_s * 1e3, 4), "traffic": traffic_l},
     }
+
+    # host-pointer entry point (what a host-resident sampler calls): includes the PCIe copies of params / results and
+    # a stream synchronize per call; reported beside `value`, never as `value`
+    host_path = None
+    if rank == 0:
+        Ph, Th = np.ascontiguousarray(P_all[sl]), np.ascontiguousarray(T_all[sl])
+        acc.set_stream(0)
+        n_h = max(10, min(args.steps, 200))
+        for g in (False, True):
+            acc.eval_batch(Ph, Th, grad=g)
+            t0 = time.perf_counter()
+            for _ in range(n_h):
+                acc.eval_batch(Ph, Th, grad=g)
+            el = time.perf_counter() - t0
+            host_path = dict(host_path or {}, **{("logL_grad" if g else "logL_only"): round(nchains * n_h / el, 1)})
+        host_path["unit"] = "chain-steps/s through tamcmc_eval_batch (host pointers, PCIe copies + sync included)"
+        acc.set_stream(stream.cuda_stream)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -178,7 +203,7 @@ def main():
                        "chains_total": total_chains, "geometry_logL": geo},
             "logL_only": {"value": round(value_l, 1), "unit": "chain-steps/s (model+logL)",
                           "ms_per_step": round(dt_l / args.steps * 1e3, 4)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "host_path": host_path, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     acc.close()

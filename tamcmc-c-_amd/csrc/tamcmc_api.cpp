@@ -1,9 +1,10 @@
 // tamcmc_api.cpp -- host side of the C ABI declared in include/tamcmc_accel.h.
 // Owns the device buffers of one context, validates arguments the way Model_def's callers rely on
-// (plength sums to Nparams, model / likelihood ids from the *.list tables), and strings the three
-// launches of one evaluation on the context stream:
-//     setup (params -> multiplet table)  ->  eval (model + likelihood [+ gradient partials])
-//     ->  finalize (fixed-order sum over tiles, -p(..)/T)  [-> backward (chain rule to d/dvars)]
+// (plength sums to Nparams, model / likelihood ids from the *.list tables), and strings the launches of
+// one evaluation on the context stream:
+//     setup (params -> multiplet table, tile descriptors)
+//     -> eval (model + likelihood; the last workgroup of a chain sums its tiles in fixed order: -p(..)/T)
+//     or eval<grad> (+ gradient partials) -> backward (tile sums, chain rule to d/dvars, logL)
 // No CPU fallback exists in this library.
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -343,7 +344,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
     return TAMCMC_OK;
 }
 
-// Enqueue setup -> eval -> finalize (-> backward) for device-resident inputs.
+// Enqueue setup -> eval (-> backward) for device-resident inputs.
 static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const double *d_T, double *d_logL,
                    double *d_grad, int32_t *d_status, const int32_t *d_rows, double *d_model)
 {

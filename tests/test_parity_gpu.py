@@ -218,3 +218,33 @@ def test_model_def_mirror(accel_mod, orc):
     assert np.max(np.abs(md.model[0] - rm) / rm) <= RTOL_MODEL
     assert np.max(np.abs(md.call_model(md.data, 0) - rm) / rm) <= RTOL_MODEL
     md.close()
+
+
+def test_large_grid_and_many_chains(accel_mod, orc):
+    """Nx = 1e6 (the reference's own row limit, config.cpp:531): 489 tiles per chain, more than one pass of the
+    setup kernel's tile loops; and 256 chains (config C3's total) in one batch."""
+    w = synth.workload_c2(Nx=1000000)
+    w["x"] = synth.grid(1000000, 2300.0, 840.0 / 1000000)
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 6)
+    T = synth.temperatures(6)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        logL, st = acc.eval_batch(P, T)
+        logLg, stg, g = acc.eval_batch(P, T, grad=True)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst) and np.array_equal(stg, rst)
+    check_logL(logL, rL)
+    check_logL(logLg, rL)
+    assert np.all(np.isfinite(g))
+    w2 = synth.workload_c2(Nx=20000)
+    y2 = spectrum_for(orc, w2)
+    P2 = synth.chain_params(w2, 256)
+    T2 = synth.temperatures(256)
+    with accel_mod.Accel(2, w2["plength"], w2["x"], y2) as acc:
+        L2, st2 = acc.eval_batch(P2, T2)
+        L2b, _ = acc.eval_batch(P2[:3], T2[:3])        # a smaller batch on the same context afterwards
+    rL2, rst2 = orc.generate_batch(2, w2["plength"], w2["x"], y2, P2, T2)
+    assert np.array_equal(st2, rst2)
+    check_logL(L2, rL2)
+    assert np.array_equal(L2b, L2[:3])

@@ -44,6 +44,24 @@ def main(out_dir):
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             d["hbm_bytes_per_launch"] = (d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
     json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    # the condensed file bench.py reads for roofline.traffic / roofline.valu
+    def pick(suffix):
+        for k in res:
+            if k.startswith("tamcmc_eval_kernel") and k.endswith(suffix):
+                return k
+        return None
+    kg, kf = pick("true>"), pick("false>")
+    if kg and kf and "hbm_bytes_per_launch" in res[kg] and "SQ_INSTS_VALU" in res[kg]:
+        hb = {"source": "%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, "
+                        "64 chains x 1e5 bins)" % os.path.basename(os.path.normpath(out_dir)),
+              "eval_grad_kernel": kg, "eval_logL_kernel": kf,
+              "eval_grad_bytes_per_launch": res[kg]["hbm_bytes_per_launch"],
+              "eval_logL_bytes_per_launch": res[kf]["hbm_bytes_per_launch"],
+              "eval_grad_valu_insts_per_launch": res[kg]["SQ_INSTS_VALU"],
+              "eval_logL_valu_insts_per_launch": res[kf]["SQ_INSTS_VALU"],
+              "clock_GHz": {"grad": out["clock_GHz_long_kernels"].get(kg), "logL": out["clock_GHz_long_kernels"].get(kf)},
+              "note": out["note"]}
+        json.dump(hb, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1, sort_keys=True)[:3000])
 
 
