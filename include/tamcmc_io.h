@@ -64,6 +64,12 @@ int tamcmc_setup_apply_phase(tamcmc_setup *s, const char *phase, int64_t Nsample
  * Modeling.prior_fct_name selects (io_MS_Global | io_local), crop the data to the model's range. */
 int tamcmc_setup_load(tamcmc_setup *s, const char *model_file, const char *data_file, int32_t slice_ind);
 
+/* Stand-alone pieces for tools (tools/getmodel.cpp:76-84): the whole .data file as a malloc'ed row-major matrix
+ * (free it with tamcmc_buffer_free), and the id of a name in a *_ctrl.list file. */
+int tamcmc_data_file_read(const char *data_file, double **data, int64_t *nrows, int32_t *ncols);
+void tamcmc_buffer_free(void *p);
+int tamcmc_list_file_lookup(const char *list_file, const char *name, int32_t *id);
+
 /* get_slices_range: the `* fmin fmax` lines of a .model file; ranges = n x 2 row-major. */
 int tamcmc_model_file_slices(const char *model_file, double *ranges, int32_t cap_rows, int32_t *n);
 

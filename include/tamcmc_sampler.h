@@ -99,10 +99,16 @@ int tamcmc_sampler_end_iteration(tamcmc_sampler *s);
 int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, int32_t *swap_hist);
 
 /* State access (local chains, row-major). which: 0 vars, 1 params, 2 logLikelihood (tempered), 3 logPrior,
- * 4 logPosterior, 5 Pmove, 6 sigma, 7 mu, 8 covarmat (n_local x Nvars x Nvars), 9 Tcoefs (local) */
+ * 4 logPosterior, 5 Pmove, 6 sigma, 7 mu, 8 covarmat (n_local x Nvars x Nvars), 9 Tcoefs (local), 10 moved (0/1) */
 int tamcmc_sampler_get(const tamcmc_sampler *s, int32_t which, double *out, int64_t capacity);
+/* Restore a saved state before tamcmc_sampler_init (Config::read_restore_files, config.cpp:1322-1577; used by
+ * Model_def's ctor, model_def.cpp:100-137, and MALA::restore_proposal, MALA.cpp:190-238).  which: 0 vars (the params
+ * rows follow), 6 sigma, 7 mu, 8 covarmat; count = number of doubles.  set_iteration = do_restore_last_index. */
+int tamcmc_sampler_set(tamcmc_sampler *s, int32_t which, const double *in, int64_t count);
+int tamcmc_sampler_set_iteration(tamcmc_sampler *s, int64_t iteration);
 int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s);
 int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s);
+int32_t tamcmc_sampler_nlocal(const tamcmc_sampler *s);   /* chains owned by this process */
 int tamcmc_sampler_destroy(tamcmc_sampler *s);
 
 /* N1 entry points, exported for tests (known answers of stats_dictionary.cpp:252-326). */

@@ -10,9 +10,10 @@ Contents (only what the hot path needs):
   model_def.py     host-side mirror of the reference's Model_def plugin surface (model_def.h:23-83)
   sampler.py       binding of include/tamcmc_sampler.h (priors, adaptive Metropolis + parallel tempering)
   setup_io.py      binding of include/tamcmc_io.h (.model / .data / .cfg / .list readers)
+  outputs.py       binding of include/tamcmc_outputs.h (result / restore files, phase driver) + readers
   synth.py         synthetic spectra / chain parameters of SURVEY.md section 8d
 """
-from . import capi, synth, model_def, shard, sampler, setup_io  # noqa: F401
+from . import capi, synth, model_def, shard, sampler, setup_io, outputs  # noqa: F401
 from .capi import Accel, AccelError, load_library, library_path  # noqa: F401
 from .model_def import ModelDef, Data  # noqa: F401
 

@@ -3,6 +3,7 @@
 // a number or a name downstream are kept and marked "quirk".
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -1212,6 +1213,35 @@ extern "C" int tamcmc_setup_apply_phase(tamcmc_setup *s, const char *phase, int6
         char b[64]; snprintf(b, sizeof(b), "%.17g", c0);
         s->cfg["MALA.c0"] = b;
     });
+}
+
+extern "C" int tamcmc_data_file_read(const char *data_file, double **data, int64_t *nrows, int32_t *ncols)
+{
+    if (!data_file || !data || !nrows || !ncols) return TAMCMC_IO_E_INVALID;
+    *data = nullptr; *nrows = 0; *ncols = 0;
+    try {
+        DataFile d = read_data_file(data_file);
+        if (d.rows.empty()) return TAMCMC_IO_E_SYNTAX;
+        double *m = (double *)malloc(sizeof(double) * d.rows.size() * d.ncols);
+        if (!m) return TAMCMC_IO_E_CAPACITY;
+        for (size_t r = 0; r < d.rows.size(); r++)
+            for (size_t c = 0; c < d.ncols; c++) m[r * d.ncols + c] = c < d.rows[r].size() ? d.rows[r][c] : std::nan("");
+        *data = m; *nrows = (int64_t)d.rows.size(); *ncols = (int32_t)d.ncols;
+        return TAMCMC_IO_OK;
+    } catch (const Fail &e) { fprintf(stderr, "tamcmc_data_file_read: %s\n", e.msg.c_str()); return e.code; }
+}
+
+extern "C" void tamcmc_buffer_free(void *p) { free(p); }
+
+extern "C" int tamcmc_list_file_lookup(const char *list_file, const char *name, int32_t *id)
+{
+    if (!list_file || !name || !id) return TAMCMC_IO_E_INVALID;
+    try {
+        const int v = read_list_file(list_file).find(name);
+        if (v == -9999) return TAMCMC_IO_E_NAME;
+        *id = v;
+        return TAMCMC_IO_OK;
+    } catch (const Fail &e) { return e.code; }
 }
 
 extern "C" int tamcmc_model_file_slices(const char *model_file, double *ranges, int32_t cap_rows, int32_t *n)

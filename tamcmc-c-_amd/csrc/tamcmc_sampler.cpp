@@ -411,6 +411,7 @@ extern "C" int tamcmc_sampler_create_hip(tamcmc_sampler **out, const tamcmc_samp
 extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; return TAMCMC_OK; }
 extern "C" int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s) { return s ? s->iter : -1; }
 extern "C" int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->Nvars : -1; }
+extern "C" int32_t tamcmc_sampler_nlocal(const tamcmc_sampler *s) { return s ? s->nloc : -1; }
 
 // model_def.cpp:139-143 + :358-367 for the starting point of every chain
 extern "C" int tamcmc_sampler_init(tamcmc_sampler *s)
@@ -656,10 +657,49 @@ extern "C" int tamcmc_sampler_get(const tamcmc_sampler *s, int32_t which, double
     case 7: v = &s->mu; break;
     case 8: v = &s->covar; break;
     case 9: tmp.assign(s->T.begin() + s->cfg.chain_offset, s->T.begin() + s->cfg.chain_offset + s->nloc); v = &tmp; break;
+    case 10: tmp.assign(s->moved.begin(), s->moved.end()); v = &tmp; break;
     default: return TAMCMC_E_INVALID;
     }
     if ((int64_t)v->size() > cap) return TAMCMC_E_INVALID;
     std::memcpy(out, v->data(), sizeof(double) * v->size());
+    return TAMCMC_OK;
+}
+
+// Restored state (Config::read_restore_files -> Model_def ctor model_def.cpp:100-137, MALA::restore_proposal
+// MALA.cpp:190-238): vars of every local chain (params rows follow), sigma, mu, covarmat.
+extern "C" int tamcmc_sampler_set(tamcmc_sampler *s, int32_t which, const double *in, int64_t count)
+{
+    if (!s || !in) return TAMCMC_E_INVALID;
+    const size_t n = (size_t)s->nloc, nv = (size_t)s->Nvars;
+    switch (which) {
+    case 0:
+        if ((size_t)count != n * nv) return TAMCMC_E_INVALID;
+        std::memcpy(s->vars.data(), in, sizeof(double) * n * nv);
+        for (size_t m = 0; m < n; m++)
+            for (size_t k = 0; k < nv; k++) s->params[m * s->Nparams + s->index_to_relax[k]] = in[m * nv + k];
+        return TAMCMC_OK;
+    case 6:
+        if ((size_t)count != n) return TAMCMC_E_INVALID;
+        std::memcpy(s->sigma.data(), in, sizeof(double) * n);
+        return TAMCMC_OK;
+    case 7:
+        if ((size_t)count != n * nv) return TAMCMC_E_INVALID;
+        std::memcpy(s->mu.data(), in, sizeof(double) * n * nv);
+        return TAMCMC_OK;
+    case 8:
+        if ((size_t)count != n * nv * nv) return TAMCMC_E_INVALID;
+        std::memcpy(s->covar.data(), in, sizeof(double) * n * nv * nv);
+        std::fill(s->chol_valid.begin(), s->chol_valid.end(), 0);
+        return TAMCMC_OK;
+    default:
+        return TAMCMC_E_INVALID;
+    }
+}
+
+extern "C" int tamcmc_sampler_set_iteration(tamcmc_sampler *s, int64_t iteration)
+{
+    if (!s || iteration < 0) return TAMCMC_E_INVALID;
+    s->iter = iteration;                       // initial_i of MALA.cpp:97-101 (do_restore_last_index)
     return TAMCMC_OK;
 }
 
