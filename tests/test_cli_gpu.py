@@ -42,7 +42,9 @@ def test_three_phase_run_from_the_reference_files(tmp_path):
 TF_3443483_local-v3   1;
 /END;
 """)
-    r = subprocess.run([exe, "execute", "1", "1", "1", "2", "3", "--root", str(root), "--seed", "42", "--quiet"],
+    # slice arguments as in main.cpp:56-61,115-126: first is 1-based inclusive, last is exclusive after the -1 shift,
+    # so "2 4" runs the slices numbered 2 and 3
+    r = subprocess.run([exe, "execute", "1", "1", "1", "2", "4", "--root", str(root), "--seed", "42", "--quiet"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     outd = tmp_path / "out" / "TF_3443483_local-v3"
