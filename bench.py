@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--nx", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-sampler", action="store_true", help="skip the end-to-end sampler rate")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -175,6 +176,25 @@ def main():
         host_path["unit"] = "chain-steps/s through tamcmc_eval_batch (host pointers, PCIe copies + sync included)"
         acc.set_stream(stream.cuda_stream)
 
+    # the whole sampler loop (SURVEY.md 8f N1+N2: proposals, priors, accept/reject, adaptation and parallel tempering in
+    # host C++; one tamcmc_eval_batch per iteration): iterations/s of MALA::execute's loop body, all chains
+    sampler_rate = None
+    if rank == 0 and world == 1 and not args.no_sampler:
+        from tamcmc_amd import sampler as S
+        cfg = S.default_cfg(nchains, seed=7, Nt_learn=(20, 60, 10 ** 9), periods_learn=(1, 1), prior_fct_switch=0, dN_mixing=1)
+        smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], w["err"])
+        smp.init()
+        smp.run(60, history=False)
+        n_s = max(50, min(2 * args.steps, 400))
+        t0 = time.perf_counter()
+        moved, _ = smp.run(n_s)
+        el = time.perf_counter() - t0
+        sampler_rate = {"iterations_per_s": round(n_s / el, 1), "chain_steps_per_s": round(nchains * n_s / el, 1),
+                        "acceptance_cold_chain": round(float(moved[:, 0].mean()), 3),
+                        "what": "adaptive Metropolis + parallel tempering (the reference's 'MALA' has no gradient), host C++ "
+                                "sampler, likelihood on the GPU through tamcmc_eval_batch (host pointers)"}
+        smp.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc       # reported baseline only; never on the product path
@@ -203,7 +223,7 @@ def main():
                        "chains_total": total_chains, "geometry_logL": geo},
             "logL_only": {"value": round(value_l, 1), "unit": "chain-steps/s (model+logL)",
                           "ms_per_step": round(dt_l / args.steps * 1e3, 4)},
-            "host_path": host_path, "roofline": roofline, "cpu_baseline": cpu,
+            "host_path": host_path, "sampler": sampler_rate, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     acc.close()

@@ -116,6 +116,9 @@ double tamcmc_logP_primitive(int32_t prior_id, const double p[4], double x);
 double tamcmc_log_prior(int32_t prior_fct_switch, int32_t Nparams, const double *params, const int32_t plength[11],
                         const int32_t *priors_names_switch, const double *priors_params, int32_t n_prior_rows,
                         const double extra_priors[4], int32_t *error);
+/* consecutive r8vec_normal_01 calls (random_JB.cpp:22-213) of the given sizes after srand(seed); split selects the
+ * one-piece routine (0) or the draw/fill pair the sampler uses (1): both must give the same numbers (test hook) */
+void tamcmc_normals(uint32_t seed, int32_t ncalls, const int32_t *sizes, double *out, int32_t split);
 /* the private copy of glibc's rand(): fills out[n] after srand(seed) (test hook) */
 void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out);
 

@@ -49,11 +49,17 @@ struct tamcmc_ctx {
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
     void *d_chain_rec = nullptr, *d_aux = nullptr;   // TmChain / TmMultFull records kept for the backward kernel
+    double *d_wt = nullptr;        // [cap][2] {T, wscale} device copies written by the setup kernel
     int32_t *d_ticket = nullptr;   // [cap] arrival counters of the in-launch finalize (kept at zero between launches)
     TmTileRec *d_trec = nullptr;   // [cap][tiles_max] tile descriptors
     int32_t *d_tidx = nullptr;     // [cap][tiles_max][n_mult] active multiplet lists
     double *d_model = nullptr;
     size_t model_cap = 0;
+    // host-pointer entry point: pinned, device-mapped staging the kernels read / write directly over PCIe
+    // (no copy-engine round trips): h_in = [params | Tcoefs], h_out = [logL | grad], h_status
+    double *h_in = nullptr, *h_out = nullptr;
+    int32_t *h_status = nullptr;
+    int h_cap = 0, h_nvars = -1;
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
@@ -152,6 +158,7 @@ static void free_batch(tamcmc_ctx *c)
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
     (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
     (void)hipFree(c->d_ticket); c->d_ticket = nullptr;
+    (void)hipFree(c->d_wt); c->d_wt = nullptr;
     c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = nullptr;
     c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
     c->cap = 0; c->cap_grad = false;
@@ -174,6 +181,7 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMalloc(&c->d_rows, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_mult, n * nm * sizeof(TmMult)));
     TM_HIP(hipMalloc(&c->d_noise, n * sizeof(TmNoise)));
+    TM_HIP(hipMalloc(&c->d_wt, n * 2 * sizeof(double)));
     TM_HIP(hipMalloc(&c->d_ticket, n * sizeof(int32_t)));
     TM_HIP(hipMemset(c->d_ticket, 0, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_trec, n * c->tiles_max * sizeof(TmTileRec)));
@@ -266,6 +274,7 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     free_batch(c);
     (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2);
     (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
+    (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -352,12 +361,12 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int K = grad ? c->Kg : c->K;
     const int S = grad ? c->Sg : c->S;
     const int tiles = grad ? c->tiles_g : c->tiles;
-    int rc = tm_launch_setup(c->L, Nchains, d_params, c->d_lx, TM_THREADS * K * S, tiles, c->d_mult, c->d_noise, c->d_trec,
+    int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K * S, tiles, c->d_mult, c->d_noise, c->d_trec,
                              c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
-    a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.Tcoefs = d_T;
+    a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.wt = c->d_wt;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
     a.row_of_chain = d_rows; a.model_out = d_model;
     a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
@@ -381,7 +390,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, d_T, c->d_chain_rec, c->d_aux,
+        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
                                 c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->Nvars, c->d_relax, d_grad, d_logL,
                                 d_status, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
@@ -425,8 +434,24 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     if (rc != TAMCMC_OK) return rc;
 
     const size_t n = (size_t)Nchains;
-    TM_HIP(hipMemcpyAsync(c->d_params, params, n * Nparams * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    TM_HIP(hipMemcpyAsync(c->d_T, Tcoefs, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (Nchains > c->h_cap || c->h_nvars != c->Nvars) {
+        TM_HIP(hipStreamSynchronize(c->stream));
+        (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
+        c->h_in = c->h_out = nullptr; c->h_status = nullptr; c->h_cap = 0;
+        const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+        const size_t cap = (size_t)(Nchains > c->cap ? Nchains : c->cap);
+        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), cap * ((size_t)Nparams + 1) * sizeof(double), flags));
+        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_out), cap * ((size_t)(c->Nvars > 0 ? c->Nvars : 0) + 1) * sizeof(double), flags));
+        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_status), cap * sizeof(int32_t), flags));
+        c->h_cap = (int)cap; c->h_nvars = c->Nvars;
+    }
+    std::memcpy(c->h_in, params, n * Nparams * sizeof(double));
+    std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
+    double *dv_in = nullptr, *dv_out = nullptr;
+    int32_t *dv_status = nullptr;
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_in), c->h_in, 0));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_out), c->h_out, 0));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_status), c->h_status, 0));
     const int32_t *d_rows = nullptr;
     if (n_rows > 0) {
         std::vector<int32_t> rows(n, -1);
@@ -442,11 +467,11 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
         TM_HIP(hipStreamSynchronize(c->stream));   // rows is a local
         d_rows = c->d_rows;
     }
-    rc = enqueue(c, Nchains, c->d_params, c->d_T, c->d_logL, grad ? c->d_grad : nullptr, c->d_status, d_rows, c->d_model);
+    // logL / status (a few hundred bytes) are written straight into the mapped host buffer by the last kernel; the
+    // gradient block goes through device memory and one copy (scattered 8-byte stores over PCIe are slow)
+    rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, grad ? c->d_grad : nullptr, dv_status, d_rows, c->d_model);
     if (rc != TAMCMC_OK) return rc;
-    TM_HIP(hipMemcpyAsync(logL, c->d_logL, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (status) TM_HIP(hipMemcpyAsync(status, c->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (grad) TM_HIP(hipMemcpyAsync(grad, c->d_grad, n * c->Nvars * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (grad) TM_HIP(hipMemcpyAsync(c->h_out + n, c->d_grad, n * (size_t)c->Nvars * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (n_rows > 0) {
         // rows whose chain was listed more than once share one device row
         for (int r = 0; r < n_rows; r++) {
@@ -458,6 +483,9 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     }
     TM_HIP(hipStreamSynchronize(c->stream));
     TM_HIP(hipGetLastError());
+    std::memcpy(logL, c->h_out, n * sizeof(double));
+    if (status) std::memcpy(status, c->h_status, n * sizeof(int32_t));
+    if (grad) std::memcpy(grad, c->h_out + n, n * (size_t)c->Nvars * sizeof(double));
     return TAMCMC_OK;
 }
 

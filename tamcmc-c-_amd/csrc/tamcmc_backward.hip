@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
         if (lane == 0) {
             double f = (L.likelihood_case == 0) ? -L.like_p * (s1 + s2) : -s1;
-            f = f / Tcoefs[chain];
+            f = f / Tcoefs[2 * chain];      // {T, wscale} pairs written by the setup kernel
             int st = noise[chain].status;
             if (st != 0) f = __builtin_nan("");
             else if (!(f == f)) st = 1;

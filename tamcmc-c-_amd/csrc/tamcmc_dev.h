@@ -87,7 +87,7 @@ struct TmEvalArgs {
     const TmNoise *noise;
     const TmTileRec *trec;      // [Nchains][tiles]
     const int32_t *tidx;        // [Nchains][tiles][n_mult] active multiplet indices, table order
-    const double *Tcoefs;
+    const double *wt;            // [Nchains][2] {Tcoefs[chain], p/T or 2/T} copied by the setup kernel into device memory
     double *part;               // [Nchains][tiles][2]
     double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL
     double *gnoise;             // [Nchains][tiles][TM_NSLOTS] or NULL
@@ -106,7 +106,7 @@ extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
 // bins_per_tile / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_lx, int bins_per_tile,
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int bins_per_tile,
                     int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
                     void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     double gn_[GRAD ? TM_GSLOTS : 1];   // GRAD: noise partial sums (3 per Harvey, sum w at slot 3*TM_MAXH, Gaussian at 13..15)
 #pragma unroll
     for (int s_ = 0; s_ < (GRAD ? TM_GSLOTS : 1); s_++) gn_[s_] = 0.0;
-    const double wscale = GRAD ? ((a.likelihood_case == 0) ? a.like_p / a.Tcoefs[chain] : 2.0 / a.Tcoefs[chain]) : 0.0;
+    const double wscale = GRAD ? a.wt[2 * chain + 1] : 0.0;
 
 #pragma unroll 1
     for (int u = 0; u < S; u++) {
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             s2 = tm_wave_sum(s2);
             if (lane == 0) {
                 double f = (a.likelihood_case == 0) ? -a.like_p * (s1 + s2) : -s1;
-                f = f / a.Tcoefs[chain];
+                f = f / a.wt[2 * chain];
                 int st = a.noise[chain].status;
                 if (st != 0) f = __builtin_nan("");
                 else if (!(f == f)) st = 1;

@@ -3,10 +3,17 @@
 // reference.  Plain C++17, no Eigen: matrices are row-major std::vector<double>.
 #include "tamcmc_sampler.h"
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -284,26 +291,136 @@ struct Rng {
             saved = 1;
         }
     }
+
+    // The same routine split in two so that the transcendental work can run on several threads: `draw` consumes
+    // the random stream exactly like normals(n, .) (and settles the carried value y, the one cross-call dependency);
+    // `NormalPlan::fill` then produces the n values from the recorded uniforms.  fill(x) == what normals(n, x) returns.
+    struct NormalPlan {
+        int n = 0, npairs = 0;         // pairs (cos, sin) written to x[first .. first + 2 npairs)
+        int first = 0;                 // 0 or 1 (x[0] taken from the carry)
+        bool has_carry_in = false, tail = false;   // tail: one more value (cos part only) after the pairs
+        double carry_in = 0.0;
+        std::vector<double> r;
+        void fill(double *x) const
+        {
+            const double PI = 3.141592653589793;
+            if (has_carry_in) x[0] = carry_in;
+            for (int k = 0; k < npairs; k++) {
+                const double a = std::sqrt(-2.0 * std::log(r[2 * k])), ang = 2.0 * PI * r[2 * k + 1];
+                x[first + 2 * k] = a * std::cos(ang);
+                x[first + 2 * k + 1] = a * std::sin(ang);
+            }
+            if (tail) x[first + 2 * npairs] = std::sqrt(-2.0 * std::log(r[2 * npairs])) * std::cos(2.0 * PI * r[2 * npairs + 1]);
+        }
+    };
+    void draw(int n, NormalPlan &P)
+    {
+        const double PI = 3.141592653589793;
+        P.n = n; P.npairs = 0; P.first = 0; P.has_carry_in = false; P.tail = false;
+        if (n <= 0) return;
+        int cnt = n;
+        if (saved == 1) { P.has_carry_in = true; P.carry_in = y; P.first = 1; saved = 0; cnt = n - 1; }
+        if (cnt == 0) return;
+        const bool odd = (cnt % 2) != 0;
+        const int nr = odd ? cnt + 1 : cnt;          // uniforms consumed (random_JB.cpp: 2 for cnt == 1, 2m otherwise)
+        if ((int)P.r.size() < nr) P.r.resize(nr);
+        for (int k = 0; k < nr; k++) P.r[k] = uniform();
+        P.npairs = cnt / 2;
+        P.tail = odd;
+        if (odd) {                                    // the sin part of the last pair is kept for the next call
+            y = std::sqrt(-2.0 * std::log(P.r[nr - 2])) * std::sin(2.0 * PI * P.r[nr - 1]);
+            saved = 1;
+        }
+    }
 };
 
-// lower Cholesky factor of an n x n SPD matrix (what tmpmat.llt().matrixL() returns, MALA.cpp:344)
-bool cholesky(const double *A, int n, double *L)
+// lower Cholesky factor of an n x n SPD matrix (what tmpmat.llt().matrixL() returns, MALA.cpp:344).
+// Right-looking form: every element still receives a_ij - l_i0 l_j0 - l_i1 l_j1 - ... in that order (the same
+// operations, in the same order, as the textbook left-looking loops), but the inner loop is a contiguous
+// elementwise update the compiler can vectorise without reassociating anything.
+__attribute__((target_clones("avx2", "default")))
+bool cholesky(const double *A, int n, double *L, double *W /* n*n + n scratch */)
 {
+    double *col = W + (size_t)n * n;
     std::memset(L, 0, sizeof(double) * (size_t)n * n);
-    for (int j = 0; j < n; j++) {
-        double d = A[(size_t)j * n + j];
-        for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) W[(size_t)i * n + j] = A[(size_t)i * n + j];
+    for (int k = 0; k < n; k++) {
+        const double d = W[(size_t)k * n + k];
         if (!(d > 0.0)) return false;
-        const double ljj = std::sqrt(d);
-        L[(size_t)j * n + j] = ljj;
-        for (int i = j + 1; i < n; i++) {
-            double v = A[(size_t)i * n + j];
-            for (int k = 0; k < j; k++) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
-            L[(size_t)i * n + j] = v / ljj;
+        const double lkk = std::sqrt(d);
+        L[(size_t)k * n + k] = lkk;
+        for (int i = k + 1; i < n; i++) { col[i] = W[(size_t)i * n + k] / lkk; L[(size_t)i * n + k] = col[i]; }
+        for (int i = k + 1; i < n; i++) {
+            const double li = col[i];
+            double *w = W + (size_t)i * n;
+            for (int j = k + 1; j <= i; j++) w[j] -= li * col[j];
         }
     }
     return true;
 }
+
+// Fork-join helper for the per-chain host work (the reference runs its chain loop under OpenMP, MALA.cpp:632).
+// Every chain's arithmetic is sequential and independent of the others, so results do not depend on the thread count.
+class ChainPool {
+public:
+    explicit ChainPool(int nthreads) { for (int t = 1; t < nthreads; t++) workers_.emplace_back([this] { loop(); }); }
+    ~ChainPool()
+    {
+        { std::lock_guard<std::mutex> g(mx_); stop_ = true; epoch_.fetch_add(1, std::memory_order_release); }
+        cv_.notify_all();
+        for (std::thread &t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    template <class F> void run(int n, F &&fn)
+    {
+        if (workers_.empty() || n < 2) { for (int i = 0; i < n; i++) fn(i); return; }
+        std::function<void(int)> job = std::ref(fn);
+        job_.store(&job, std::memory_order_relaxed); n_.store(n, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed); next_.store(0, std::memory_order_release);
+        { std::lock_guard<std::mutex> g(mx_); epoch_.fetch_add(1, std::memory_order_release); }
+        cv_.notify_all();
+        work();
+        while (done_.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        // a worker may still be between its last fetch of next_ and its return from work(): it touches only
+        // members, never `job`, after done_ reached n
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (i >= n_.load(std::memory_order_relaxed)) return;
+            (*job_.load(std::memory_order_relaxed))(i);
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            // spin for a while (the next fork usually comes within one GPU evaluation), then sleep
+            uint64_t e = epoch_.load(std::memory_order_acquire);
+            for (int spin = 0; e == seen && spin < 40000; spin++) { __builtin_ia32_pause(); e = epoch_.load(std::memory_order_acquire); }
+            if (e == seen) {
+                std::unique_lock<std::mutex> g(mx_);
+                cv_.wait(g, [&] { return epoch_.load(std::memory_order_acquire) != seen; });
+                e = epoch_.load(std::memory_order_acquire);
+            }
+            seen = e;
+            if (stop_) return;
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mx_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> epoch_{0};
+    std::atomic<int> next_{1 << 30}, done_{0}, n_{0};
+    std::atomic<const std::function<void(int)> *> job_{nullptr};
+    bool stop_ = false;
+};
 
 double min1(double e)   // VectorXd(1., e).minCoeff() with the scalar visitor: NaN never replaces 1
 {
@@ -334,8 +451,10 @@ struct tamcmc_sampler {
     std::vector<double> covar, sigma, mu, Lchol;
     std::vector<uint8_t> chol_valid;
     // scratch
-    std::vector<double> p_prop, v_prop, L_prop, u_mh, z;
+    std::vector<double> p_prop, v_prop, L_prop, u_mh, z, z_all, chol_scratch;
     std::vector<int32_t> status;
+    std::vector<Rng::NormalPlan> plans;          // one per local chain (+1 for chains owned elsewhere)
+    std::unique_ptr<ChainPool> pool;
     Rng rng;
     int64_t iter = 0;
     int64_t bad_chol = 0;
@@ -388,6 +507,16 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
     }
     s->p_prop.resize((size_t)n * Nparams); s->v_prop.resize((size_t)n * nv); s->L_prop.resize(n);
     s->u_mh.resize(n); s->z.resize(nv); s->status.resize(n);
+    s->plans.resize((size_t)n + 1);
+    s->z_all.resize((size_t)n * nv); s->chol_scratch.resize((size_t)n * (2 * (size_t)nv * nv + nv));
+    {   // host threads for the per-chain work: TAMCMC_SAMPLER_THREADS, default min(cores, 16, chains)
+        int nt = (int)std::thread::hardware_concurrency();
+        if (nt > 16) nt = 16;
+        if (const char *e = std::getenv("TAMCMC_SAMPLER_THREADS")) nt = std::atoi(e);
+        if (nt > n) nt = n;
+        if (nt < 1) nt = 1;
+        s->pool.reset(new ChainPool(nt));
+    }
     s->rng.g.seed(cfg->seed);
     *out = s;
     return TAMCMC_OK;
@@ -479,40 +608,49 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     const int n = s->nloc, nv = s->Nvars, np = s->Nparams, off = s->cfg.chain_offset;
     const int64_t i = s->iter;
     const double gamma = s->cfg.c0 / (1. + (double)i);             // MALA.cpp:630
-    std::vector<double> tmp((size_t)nv * nv);
-    // 1. proposals, in the reference's draw order: for each chain, u then z (MALA.cpp:451,465,346)
+    // 1. proposals.  Random draws first, in the reference's order: for each chain, u then z (MALA.cpp:451,465,346);
+    //    then the per-chain linear algebra, chains in parallel.
     for (int g = 0; g < s->cfg.Nchains; g++) {
         const double u = s->rng.uniform();
-        s->rng.normals(nv, s->z.data());
         const int m = g - off;
-        if (m < 0 || m >= n) continue;
-        s->u_mh[m] = u;
+        const bool mine = (m >= 0 && m < n);
+        s->rng.draw(nv, s->plans[mine ? (size_t)m : (size_t)n]);
+        if (mine) s->u_mh[m] = u;
+    }
+    std::atomic<int64_t> bad{0};
+    s->pool->run(n, [&](int m) {
         if (!s->chol_valid[m]) {
+            double *tmp = &s->chol_scratch[(size_t)m * (2 * (size_t)nv * nv + nv)];
             const double *C = &s->covar[(size_t)m * nv * nv];
             for (int a = 0; a < nv; a++)
                 for (int b = 0; b < nv; b++)
                     tmp[(size_t)a * nv + b] = (C[(size_t)a * nv + b] + (a == b ? s->cfg.epsilon2 : 0.0)) * s->sigma[m];   // :342
-            if (!cholesky(tmp.data(), nv, &s->Lchol[(size_t)m * nv * nv])) s->bad_chol++;
+            if (!cholesky(tmp, nv, &s->Lchol[(size_t)m * nv * nv], tmp + (size_t)nv * nv)) bad.fetch_add(1, std::memory_order_relaxed);
             s->chol_valid[m] = 1;
         }
+        double *z = &s->z_all[(size_t)m * nv];
+        s->plans[m].fill(z);
         const double *Lc = &s->Lchol[(size_t)m * nv * nv];
         for (int a = 0; a < nv; a++) {
             double acc = 0.0;
-            for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * s->z[b];
+            for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * z[b];
             s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + acc;             // :349
         }
         std::memcpy(&s->p_prop[(size_t)m * np], &s->params[(size_t)m * np], sizeof(double) * np);
         for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
-    }
+    });
+    s->bad_chol += bad.load();
     // 2. the hot path: every local chain in one call
     int rc = s->eval(s->eval_user, n, np, s->p_prop.data(), &s->T[off], s->L_prop.data(), s->status.data());
     if (rc != TAMCMC_OK) return rc;
     // 3. accept / reject and adaptation, MALA.cpp:475-534, :641-652
     int64_t period = 1;
     const bool learn = learning_now(s, i, &period);
-    int perr = 0;
-    for (int m = 0; m < n; m++) {
+    std::atomic<int> perr_any{0};
+    s->pool->run(n, [&](int m) {
+        int perr = 0;
         const double lpr = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+        if (perr) perr_any.store(1, std::memory_order_relaxed);
         const double lpo = s->L_prop[m] + lpr;
         double r;
         if (!std::isnan(s->L_prop[m])) {
@@ -531,7 +669,8 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         }
         s->Pmove[m] = r;
         if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
-    }
+    });
+    const int perr = perr_any.load();
     return perr ? TAMCMC_E_INVALID : TAMCMC_OK;
 }
 
@@ -722,6 +861,20 @@ extern "C" double tamcmc_log_prior(int32_t fct, int32_t Nparams, const double *p
     const double v = (double)log_prior(S, params, &err);
     if (error) *error = err;
     return v;
+}
+
+// test hook: consecutive r8vec_normal_01 calls of the given sizes after srand(seed); split = 0 uses the one-piece
+// routine, 1 the draw / fill pair the sampler runs on several threads
+extern "C" void tamcmc_normals(uint32_t seed, int32_t ncalls, const int32_t *sizes, double *out, int32_t split)
+{
+    Rng rng;
+    rng.g.seed(seed);
+    Rng::NormalPlan plan;
+    for (int c = 0; c < ncalls; c++) {
+        if (split) { rng.draw(sizes[c], plan); plan.fill(out); }
+        else rng.normals(sizes[c], out);
+        out += sizes[c];
+    }
 }
 
 extern "C" void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out)

@@ -11,6 +11,7 @@
 
 #define TM_SETUP_THREADS 128   // wave 0: chain record + multiplets; wave 1 lane 0: noise record, concurrently
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
+                                                          const double *__restrict__ Tcoefs, double *__restrict__ wt,
                                                           const double *__restrict__ lx, int TB, int tiles,
                                                           TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
                                                           TmTileRec *__restrict__ trec, int32_t *__restrict__ tidx,
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
 #endif
     if (tid == 64) {
         s_N.status = s_status;
+        const double Tc = Tcoefs[chain];     // the caller's array may live in host memory: read once, keep a device copy
+        wt[2 * chain] = Tc;
+        wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
         noise[chain] = s_N;
     }
 
@@ -172,12 +176,12 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
     }
 }
 
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_lx, int bins_per_tile,
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int bins_per_tile,
                     int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
                     void *d_chain_rec, void *d_aux, void *stream)
 {
     hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
-                       d_params, d_lx, bins_per_tile, tiles, d_mult, d_noise, d_trec, d_tidx,
+                       d_params, d_Tcoefs, d_wt, d_lx, bins_per_tile, tiles, d_mult, d_noise, d_trec, d_tidx,
                        static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux));
     return (int)hipGetLastError();
 }

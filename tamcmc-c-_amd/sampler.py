@@ -50,6 +50,8 @@ def _lib():
         lib.tamcmc_logP_primitive.restype = C.c_double
         lib.tamcmc_log_prior.argtypes = [C.c_int32, C.c_int32, dp, ip, ip, dp, C.c_int32, dp, ip]
         lib.tamcmc_log_prior.restype = C.c_double
+        lib.tamcmc_normals.argtypes = [C.c_uint32, C.c_int32, ip, dp, C.c_int32]
+        lib.tamcmc_normals.restype = None
         lib.tamcmc_glibc_rand.argtypes = [C.c_uint32, C.c_int32, ip]
         lib.tamcmc_glibc_rand.restype = None
         _BOUND = True
@@ -86,6 +88,13 @@ def log_prior(prior_fct_switch, params, plength, priors_names_switch, priors_par
 def glibc_rand(seed, n):
     out = np.empty(n, dtype=np.int32)
     _lib().tamcmc_glibc_rand(int(seed), n, _ip(out))
+    return out
+
+
+def normals(seed, sizes, split=False):
+    sz = np.ascontiguousarray(sizes, dtype=np.int32)
+    out = np.empty(int(sz.sum()))
+    _lib().tamcmc_normals(int(seed), sz.size, _ip(sz), _dp(out), 1 if split else 0)
     return out
 
 

@@ -193,3 +193,32 @@ def test_sampler_rejects_nan_and_minus_infinity(orc):
     smp, moved, _, _, _ = make_run(orc, make, n_iter=30, cfg_kw=dict(dN_mixing=10**9), nchains=4)   # no PT: states stay in their slot
     assert moved[:, 1].sum() == 0 and moved[:, 0].sum() > 0
     assert np.all(smp.get("Pmove")[1] == 0.0)
+
+
+def test_split_normal_generator_equals_the_one_piece_routine():
+    """The sampler draws the random stream sequentially and leaves the Box-Muller transforms to worker threads;
+    that pair must reproduce r8vec_normal_01 (random_JB.cpp:22-213) value for value, carried sine included."""
+    sizes = [3, 4, 1, 5, 2, 2, 7, 1, 1, 44, 9, 10]
+    a = S.normals(123, sizes, split=False)
+    b = S.normals(123, sizes, split=True)
+    assert np.array_equal(a, b) and np.all(np.isfinite(a)) and abs(a.mean()) < 0.5
+
+
+def test_thread_count_does_not_change_the_chains(orc, monkeypatch):
+    w, sw, pp, b = ms_global_prior_setup()
+    w = dict(w); w["x"] = synth.grid(1500, 2300.0, 840.0 / 1500)
+    m, _ = orc.model(3, w["params_true"], w["plength"], w["x"])
+    y = synth.make_spectrum(m, seed=3)
+    out = []
+    for nt in ("1", "3", "8"):
+        monkeypatch.setenv("TAMCMC_SAMPLER_THREADS", nt)
+        cfg = S.default_cfg(6, seed=77, Nt_learn=(5, 30, 100000), periods_learn=(1, 2), prior_fct_switch=2, dN_mixing=3)
+        smp = S.Sampler(cfg, oracle_evaluator(orc, 3, w, y), w["plength"], w["params_true"], w["relax"], w["err"], sw, pp,
+                        [1.0, 5.0, 0.5, 0.0])
+        smp.init()
+        mv, sws = smp.run(60)
+        out.append((mv, sws, smp.get("vars"), smp.get("covarmat"), smp.get("sigma")))
+        smp.close()
+    for o in out[1:]:
+        for a, b2 in zip(out[0], o):
+            assert np.array_equal(a, b2)
