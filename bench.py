@@ -168,11 +168,15 @@ def main():
         n_h = max(10, min(args.steps, 200))
         for g in (False, True):
             acc.eval_batch(Ph, Th, grad=g)
-            t0 = time.perf_counter()
-            for _ in range(n_h):
+            dts = np.empty(n_h)
+            for k in range(n_h):
+                t0 = time.perf_counter()
                 acc.eval_batch(Ph, Th, grad=g)
-            el = time.perf_counter() - t0
-            host_path = dict(host_path or {}, **{("logL_grad" if g else "logL_only"): round(nchains * n_h / el, 1)})
+                dts[k] = time.perf_counter() - t0
+            key = "logL_grad" if g else "logL_only"
+            host_path = dict(host_path or {}, **{key: round(nchains * n_h / dts.sum(), 1),
+                                                 key + "_median_call_us": round(float(np.median(dts)) * 1e6, 1),
+                                                 key + "_max_call_us": round(float(dts.max()) * 1e6, 1)})
         host_path["unit"] = "chain-steps/s through tamcmc_eval_batch (host pointers, PCIe copies + sync included)"
         acc.set_stream(stream.cuda_stream)
 

@@ -60,6 +60,7 @@ struct tamcmc_ctx {
     double *h_in = nullptr, *h_out = nullptr;
     int32_t *h_status = nullptr;
     int h_cap = 0, h_nvars = -1;
+    hipEvent_t ev_done = nullptr;  // completion of a host-pointer call, polled (see wait_done)
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
@@ -275,6 +276,7 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2);
     (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
     (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -417,6 +419,21 @@ extern "C" int tamcmc_eval_batch_device(tamcmc_ctx *c, int32_t Nchains, int32_t 
     return enqueue(c, Nchains, d_params, d_Tcoefs, d_logL, d_grad, d_status, nullptr, nullptr);
 }
 
+// Wait for everything enqueued so far by polling an event.  hipStreamSynchronize may park the calling thread on an
+// interrupt; on this platform that path showed rare stalls of 1-40 ms after a ~160 us batch (profiles/README.md),
+// and a sampler calls this thousands of times per second.
+static int wait_done(tamcmc_ctx *c)
+{
+    if (!c->ev_done) TM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    TM_HIP(hipEventRecord(c->ev_done, c->stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(c->ev_done);
+        if (e == hipSuccess) return TAMCMC_OK;
+        if (e != hipErrorNotReady) { snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e)); return TAMCMC_E_HIP; }
+        __builtin_ia32_pause();
+    }
+}
+
 extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams,
                                  const double *params, const double *Tcoefs,
                                  double *logL, double *grad,
@@ -481,7 +498,8 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
                                   (size_t)c->L.Nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
     }
-    TM_HIP(hipStreamSynchronize(c->stream));
+    rc = wait_done(c);
+    if (rc != TAMCMC_OK) return rc;
     TM_HIP(hipGetLastError());
     std::memcpy(logL, c->h_out, n * sizeof(double));
     if (status) std::memcpy(status, c->h_status, n * sizeof(int32_t));
