@@ -196,7 +196,19 @@ def main():
         sampler_rate = {"iterations_per_s": round(n_s / el, 1), "chain_steps_per_s": round(nchains * n_s / el, 1),
                         "acceptance_cold_chain": round(float(moved[:, 0].mean()), 3),
                         "what": "adaptive Metropolis + parallel tempering (the reference's 'MALA' has no gradient), host C++ "
-                                "sampler, likelihood on the GPU through tamcmc_eval_batch (host pointers)"}
+                                "sampler, likelihood on the GPU through tamcmc_eval_batch (host pointers); proposal adapted "
+                                "every iteration (Burn-in / Learning phases)"}
+        smp.close()
+        # Acquire phase: the proposal is frozen (config_presets.cpp:87-92), so no Cholesky per iteration
+        cfg = S.default_cfg(nchains, seed=7, Nt_learn=(10 ** 9, 10 ** 9 + 1, 10 ** 9 + 2), periods_learn=(1, 1), prior_fct_switch=0, dN_mixing=1)
+        smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], 0.05 * w["err"])
+        smp.init()
+        smp.run(20, history=False)
+        t0 = time.perf_counter()
+        smp.run(n_s, history=False)
+        el = time.perf_counter() - t0
+        sampler_rate["acquire_phase_iterations_per_s"] = round(n_s / el, 1)
+        sampler_rate["acquire_phase_chain_steps_per_s"] = round(nchains * n_s / el, 1)
         smp.close()
 
     cpu = None
