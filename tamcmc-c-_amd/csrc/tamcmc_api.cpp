@@ -31,10 +31,15 @@ static thread_local char g_hip_err[256] = "";
 struct tamcmc_ctx {
     int device = 0;
     TmLayout L{};
-    int K = 4, S = 2;              // likelihood only: KU bins in flight per thread, S sub-blocks -> 2048-bin tiles
-    int Kg = 2, Sg = 8;            // with gradient partials: 4096-bin tiles, 2 bins in flight (3 waves per SIMD)
-    int tiles = 0;                 // tiles at K
-    int tiles_g = 0;               // tiles at Kg
+    // Tile geometry.  The grid is cut into `units` sub-blocks of 256*KU bins, spread over T = ceil(units / S) tiles
+    // (sizes differ by at most one sub-block); S / Sg bound the tile size (Sg also bounds the LDS of pass 2).
+    int K = 4, S = 2;              // likelihood only: KU bins in flight per thread, at most S sub-blocks (2048 bins) per tile
+    int Kg = 2, Sg = 7;            // with gradient partials: 2 bins in flight, at most 7 sub-blocks (3584 bins, 28 KB of LDS)
+    int units = 0, units_g = 0;    // sub-blocks in the grid at K / Kg
+    int tiles_cap = 0, tiles_g_cap = 0;   // largest T pick_tiles may return (buffers are sized for it)
+    int force_tiles = 0, force_tiles_g = 0;   // developer knobs TAMCMC_TILES / TAMCMC_TILES_GRAD
+    int slots = 0, slots_g = 0;    // resident workgroups of the two kernels on this device
+    int last_tiles = 0;            // T of the most recent likelihood-only call (tamcmc_ctx_geometry)
     int tiles_max = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -69,6 +74,8 @@ struct tamcmc_ctx {
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
     size_t ev_used = 0;
 };
+
+static int pick_tiles(const tamcmc_ctx *c, int Nchains, bool grad);
 
 static int model_supported(int id)
 {
@@ -188,8 +195,8 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMalloc(&c->d_trec, n * c->tiles_max * sizeof(TmTileRec)));
     TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(int32_t)));
     if (g) {
-        TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g * nm * TM_GSLOTS * sizeof(double)));
-        TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g * TM_NSLOTS * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g_cap * nm * TM_GSLOTS * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g_cap * TM_NSLOTS * sizeof(double)));
         const int nv = c->Nvars > 0 ? c->Nvars : 1;
         TM_HIP(hipMalloc(&c->d_grad, n * nv * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_chain_rec, n * tm_sizeof_chain_rec()));
@@ -235,19 +242,39 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_S", 1, 64, &c->S);
     env_int("TAMCMC_KU_GRAD", 1, 4, &c->Kg);
     env_int("TAMCMC_S_GRAD", 1, 16, &c->Sg);
+    env_int("TAMCMC_TILES", 1, 1 << 20, &c->force_tiles);
+    env_int("TAMCMC_TILES_GRAD", 1, 1 << 20, &c->force_tiles_g);
     if (c->K == 3) c->K = 4;
     if (c->Kg == 3) c->Kg = 2;
     {
-        const int64_t TB = (int64_t)TM_THREADS * c->K * c->S, TBg = (int64_t)TM_THREADS * c->Kg * c->Sg;
-        c->tiles = (int)((Nx + TB - 1) / TB);
-        c->tiles_g = (int)((Nx + TBg - 1) / TBg);
+        const int64_t UB = (int64_t)TM_THREADS * c->K, UBg = (int64_t)TM_THREADS * c->Kg;
+        c->units = (int)((Nx + UB - 1) / UB);
+        c->units_g = (int)((Nx + UBg - 1) / UBg);
+        auto cap_of = [](int units, int Smax) {
+            const int tmin = (units + Smax - 1) / Smax;
+            int cap = 2 * tmin + 8;                      // room for finer tilings that fill whole rounds
+            return cap > units ? units : cap;
+        };
+        c->tiles_cap = cap_of(c->units, c->S);
+        c->tiles_g_cap = cap_of(c->units_g, c->Sg);
+        if (c->force_tiles > c->tiles_cap) c->tiles_cap = c->force_tiles > c->units ? c->units : c->force_tiles;
+        if (c->force_tiles_g > c->tiles_g_cap) c->tiles_g_cap = c->force_tiles_g > c->units_g ? c->units_g : c->force_tiles_g;
     }
-    c->tiles_max = c->tiles > c->tiles_g ? c->tiles : c->tiles_g;
+    c->tiles_max = c->tiles_cap > c->tiles_g_cap ? c->tiles_cap : c->tiles_g_cap;
 
     auto fail = [&](int code) { tamcmc_ctx_destroy(c); return code; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(TAMCMC_E_NODEVICE);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(TAMCMC_E_HIP);
     c->stream = c->own_stream;
+    {   // resident workgroups: the likelihood kernel fits 7 per CU (registers), the gradient kernel 4 (LDS, registers)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < 1) cus = 256;
+        c->slots = cus * 7;
+        c->slots_g = cus * 4;
+        int v = 0;
+        const char *e = getenv("TAMCMC_SLOTS");      if (e && (v = atoi(e)) > 0) c->slots = v;
+        e = getenv("TAMCMC_SLOTS_GRAD");             if (e && (v = atoi(e)) > 0) c->slots_g = v;
+    }
     const size_t bytes = (size_t)Nx * sizeof(double);
     if (hipMalloc(&c->d_x, bytes) != hipSuccess || hipMalloc(&c->d_y, bytes) != hipSuccess ||
         hipMalloc(&c->d_lx, bytes) != hipSuccess)
@@ -348,11 +375,24 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
                                    int32_t *n_multiplets)
 {
     if (!c) return TAMCMC_E_INVALID;
-    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K * c->S;
-    if (tiles) *tiles = c->tiles;
+    const int T = c->last_tiles > 0 ? c->last_tiles : pick_tiles(c, 64, false);
+    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K * ((c->units + T - 1) / T);   // the largest tile
+    if (tiles) *tiles = T;
     if (threads_per_block) *threads_per_block = TM_THREADS;
     if (n_multiplets) *n_multiplets = c->L.n_mult;
     return TAMCMC_OK;
+}
+
+// Number of tiles.  It depends on the grid only, never on the batch: a chain's result must not change with the number
+// of chains evaluated beside it (a sharded run and a single-process run have to produce bit-identical chains).
+static int pick_tiles(const tamcmc_ctx *c, int /*Nchains*/, bool grad)
+{
+    const int units = grad ? c->units_g : c->units, Smax = grad ? c->Sg : c->S;
+    const int cap = grad ? c->tiles_g_cap : c->tiles_cap, forced = grad ? c->force_tiles_g : c->force_tiles;
+    int tmin = (units + Smax - 1) / Smax;
+    if (tmin > cap) tmin = cap;
+    if (forced > 0) return forced < tmin ? tmin : (forced > cap ? cap : forced);
+    return tmin;
 }
 
 // Enqueue setup -> eval (-> backward) for device-resident inputs.
@@ -361,9 +401,10 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
 {
     const bool grad = d_grad != nullptr;
     const int K = grad ? c->Kg : c->K;
-    const int S = grad ? c->Sg : c->S;
-    const int tiles = grad ? c->tiles_g : c->tiles;
-    int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K * S, tiles, c->d_mult, c->d_noise, c->d_trec,
+    const int units = grad ? c->units_g : c->units;
+    const int tiles = pick_tiles(c, Nchains, grad);
+    if (!grad) c->last_tiles = tiles;
+    int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, tiles, c->d_mult, c->d_noise, c->d_trec,
                              c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
@@ -374,7 +415,9 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
-    a.S = S;
+    a.units = units;
+    a.tile_q = units / tiles; a.tile_rem = units % tiles;
+    a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     if (c->profile) {
         while (c->ev.size() < c->ev_used + 2) {
             hipEvent_t e;
@@ -392,7 +435,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K * S, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
+        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K, units, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
                                 c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->Nvars, c->d_relax, d_grad, d_logL,
                                 d_status, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }

@@ -36,7 +36,7 @@ __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + 
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
 #define TM_BW_THREADS 256
-__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int TB,
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int UB, int units,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmChain *__restrict__ chain_rec,
@@ -117,8 +117,12 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const TmMultFull &M = auxp[j];
         double acc = 0.0;
         if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
-            const int t0 = M.imin / TB, t1 = (M.imax - 1) / TB;
-            for (int t = t0; t <= t1 && t < tiles; t++)
+            // tiles whose sub-block range [TM_TILE_U0(t), TM_TILE_U0(t+1)) meets the window's sub-blocks [ua, ub]
+            const int ua = M.imin / UB, ub = (M.imax - 1) / UB;
+            const int tq = units / tiles, trem = units % tiles;
+            int t0 = (ua < trem * (tq + 1)) ? ua / (tq + 1) : trem + (ua - trem * (tq + 1)) / tq;
+            if (t0 > tiles - 1) t0 = tiles - 1;
+            for (int t = t0; t < tiles && TM_TILE_U0Q(t, tq, trem) <= ub; t++)
                 acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
         }
         s_G[item] = acc;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     }
 }
 
-int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins, int units, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise,
                        int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
@@ -424,7 +428,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_t
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
-                       bins_per_tile, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
+                       unit_bins, units, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
                        static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, Nvars,
                        d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();

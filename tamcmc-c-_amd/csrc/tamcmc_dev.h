@@ -97,23 +97,31 @@ struct TmEvalArgs {
     const int32_t *row_of_chain;// NULL or [Nchains]: row of model_out to fill, -1 none
     double *model_out;
     int32_t Nx, n_mult, tiles, likelihood_case;
-    int32_t S, pad;             // sub-blocks of 256*KU bins per tile
+    int32_t units, pad;         // the grid is cut into `units` sub-blocks of 256*KU bins; tile t owns sub-blocks
+                                // [TM_TILE_U0(t), TM_TILE_U0(t+1)): sizes differ by at most one sub-block
+    int32_t tile_q, tile_rem;   // units / tiles, units % tiles
     double like_p;
+    unsigned long long tile_magic;   // ceil(2^40 / tiles): n / tiles == (n * tile_magic) >> 40 for n < 2^20 (slot -> tile rotation)
 };
+
+// first sub-block of tile t when `units` sub-blocks are spread over `tiles` tiles as evenly as possible: with
+// q = units / tiles and rem = units % tiles the first `rem` tiles own q + 1 sub-blocks, the others q (no division)
+#define TM_TILE_U0Q(t, q, rem) ((int)(t) * (int)(q) + ((int)(t) < (int)(rem) ? (int)(t) : (int)(rem)))
+#define TM_TILE_U0(t, units, tiles) TM_TILE_U0Q(t, (units) / (tiles), (units) % (tiles))
 
 #ifdef __cplusplus
 extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
-// bins_per_tile / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int bins_per_tile,
-                    int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
+// unit_bins / units / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
+                    int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
                     void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
-int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int bins_per_tile, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins, int units, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise,
                        int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,

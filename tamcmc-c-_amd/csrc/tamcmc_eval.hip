@@ -35,6 +35,9 @@
 //   counter, never a floating-point accumulation: results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #define TM_WAVES (TM_THREADS / 64)
 
@@ -268,17 +271,37 @@ __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restric
 #ifndef TM_LB_GRAD
 #define TM_LB_GRAD 3   // same for the gradient kernel: 155 VGPRs at KU=2 once the multiplet records live in SGPRs
 #endif
+#ifdef TM_TRACE   // developer build: per-workgroup time stamps (tools/block_trace.py)
+__device__ unsigned long long *g_tm_trace = nullptr;
+#define TM_STAMP(slot) do { if (threadIdx.x == 0 && g_tm_trace) g_tm_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TM_STAMP(slot) do { } while (0)
+#endif
 template <int KU, bool GRAD>
 __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
 {
-    const int S = a.S;
-    const int TB = TM_THREADS * KU * S;
+    TM_STAMP(0);
+    // Workgroups go to the 8 XCDs round-robin by linear id (slot + tiles * chain).  Tile costs follow the mode
+    // pattern of the spectrum, so every XCD should see every tile equally often.  With tile = slot that holds only
+    // when tiles = 1 (mod 8); a tile count that is a multiple of 8 pins each tile to one XCD and the XCD with the
+    // densest tiles finishes ~15 % late (profiles/README.md).  Rotating the slot -> tile map by r * chain with
+    // r = (tiles - 1) mod 8 makes (XCD - tile) = chain (mod 8) for every tile count.
+    const int chain = blockIdx.y, tid = threadIdx.x;
+    TmNoiseK sn = (TmNoiseK)(a.noise + chain);
+    const unsigned rn = (unsigned)((a.tiles - 1) & 7) * (unsigned)(chain & 0xffff);          // < 2^19
+    const unsigned rq = (unsigned)(((unsigned long long)rn * a.tile_magic) >> 40);           // rn / tiles (scalar unit)
+    int tile = (int)blockIdx.x + (int)(rn - rq * (unsigned)a.tiles);
+    if (tile >= a.tiles) tile -= a.tiles;
+    const int u_first = TM_TILE_U0Q(tile, a.tile_q, a.tile_rem);
+    const int S = a.tile_q + (tile < a.tile_rem ? 1 : 0);             // sub-blocks of this tile
     constexpr int KU2 = (KU > 2) ? 2 : KU;   // pass 2 keeps 3 accumulators per component: fewer bins in flight
     const int Sp2 = S * (KU / KU2);          // sub-blocks of pass 2
-    const int tile = blockIdx.x, chain = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int base = tile * TB;
+    const int base = u_first * (TM_THREADS * KU);
 
+#if defined(TM_ABLATE) && (TM_ABLATE & 16)   // timing-only build: empty workgroups (dispatch cost only)
+    if (a.Nx > 0) return;
+#endif
     extern __shared__ double s_dyn[];
     double *s_w = s_dyn;                                             // [TM_THREADS * KU * S]   (GRAD only)
     __shared__ double s_red[2][TM_WAVES][TM_GSLOTS];   // double-buffered: one barrier per multiplet in pass 2
@@ -289,7 +312,6 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     // wave-uniform: it is fetched with s_load into SGPRs.  No LDS staging, no barrier before the first bin.
     const TmMult *__restrict__ gm = a.mult + (size_t)chain * a.n_mult;
     TmTileRecK tr = (TmTileRecK)(a.trec + (size_t)chain * a.tiles + tile);
-    TmNoiseK sn = (TmNoiseK)(a.noise + chain);
     TmIdxK tix = (TmIdxK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
     const int nh = sn->nh;
     const int nact = tr->nact;
@@ -299,6 +321,9 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     const double N0 = sn->N0;
     const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
 
+#if defined(TM_ABLATE) && (TM_ABLATE & 32)   // timing-only build: prologue (scalar loads) only
+    if (nact >= 0 && lxc == lxc && N0 == N0) { if (tid == 0 && !GRAD) a.part[((size_t)chain * a.tiles + tile) * 2] = (double)(nh + row + (npoly ? 1 : 0) + (has_gauss ? 1 : 0)); return; }
+#endif
     // ---------------- pass 1: model spectrum and likelihood partial sums ----------------
     double S1 = 0.0;
     double P = 1.0;
@@ -474,11 +499,16 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             }
         }
     }
+    TM_STAMP(1);
     double S2 = 0.0;
+#if defined(TM_ABLATE) && (TM_ABLATE & 8)    // timing-only build: no log in the epilogue
+    S2 = P + (double)esum + Mmin;
+#else
     if (a.likelihood_case == 0) {
         S2 = log(P) + (double)esum * 0.693147180559945309417232;
         if (!(Mmin > 0.0)) S2 = __builtin_nan("");
     }
+#endif
     S1 = tm_wave_sum(S1);
     S2 = tm_wave_sum(S2);
     if (lane == 0) { s_red[0][wave][0] = S1; s_red[0][wave][1] = S2; }
@@ -504,11 +534,15 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             double t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
+#if defined(TM_ABLATE) && (TM_ABLATE & 4)    // timing-only build: plain stores, no ticket, no finalize
+            pp[2 * tile] = t1; pp[2 * tile + 1] = t2;
+#else
             __hip_atomic_store(pp + 2 * tile, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(pp + 2 * tile + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int prev = __hip_atomic_fetch_add(a.ticket + chain, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (prev == a.tiles - 1) ? 1 : 0;
+#endif
         }
         last = __shfl(last, 0, 64);
         if (last) {
@@ -532,6 +566,16 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
         }
     }
 
+    TM_STAMP(2);
+#ifdef TM_TRACE
+    if (threadIdx.x == 0 && g_tm_trace) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_tm_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // ---------------- pass 2: gradient partial sums ----------------
     if constexpr (GRAD) {
         __syncthreads();   // s_red[0] (likelihood) consumed; s_w complete
@@ -593,15 +637,36 @@ template <int KU>
 static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
 {
     dim3 grid(a.tiles, Nchains), block(TM_THREADS);
-    size_t lds = grad ? (size_t)TM_THREADS * KU * a.S * sizeof(double) : 8;
+    const int Smax = (a.units + a.tiles - 1) / a.tiles;
+    size_t lds = grad ? (size_t)TM_THREADS * KU * Smax * sizeof(double) : 8;
     if (lds > 48 * 1024) {
         const void *fn = grad ? reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, true>)
                               : reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, false>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+#ifdef TM_TRACE
+    static unsigned long long *d_trace = nullptr;
+    static size_t cap = 0;
+    const size_t nblk = (size_t)a.tiles * Nchains;
+    const char *tf = getenv("TAMCMC_TRACE_FILE");
+    if (tf && !grad) {
+        if (nblk > cap) { (void)hipFree(d_trace); (void)hipMalloc(&d_trace, nblk * 4 * sizeof(unsigned long long)); cap = nblk; }
+        (void)hipMemsetAsync(d_trace, 0, nblk * 4 * sizeof(unsigned long long), stream);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tm_trace), &d_trace, sizeof(d_trace), 0, hipMemcpyHostToDevice, stream);
+    }
+#endif
     if (grad) hipLaunchKernelGGL((tamcmc_eval_kernel<KU, true>), grid, block, lds, stream, a);
     else      hipLaunchKernelGGL((tamcmc_eval_kernel<KU, false>), grid, block, lds, stream, a);
+#ifdef TM_TRACE
+    if (tf && !grad) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(nblk * 4);
+        (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        FILE *f = fopen(tf, "wb");
+        if (f) { long long dims[2] = {a.tiles, Nchains}; fwrite(dims, sizeof(dims), 1, f); fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
+#endif
     return (int)hipGetLastError();
 }
 
