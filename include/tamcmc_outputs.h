@@ -51,6 +51,14 @@ int tamcmc_outputs_create(tamcmc_outputs **out, const tamcmc_setup *setup, int32
  * MALA::execute passes them (chain_A = -1 and Pswap = last value when no attempt was made). */
 int tamcmc_outputs_record(tamcmc_outputs *o, const tamcmc_sampler *s, int32_t attempted, int32_t chain_A, double Pswap,
                           int32_t swapped);
+/* A whole block of n <= Nbuffer samples at once, from arrays covering ALL chains (sharded runs: rank 0 gathers the
+ * ranks' local blocks, tamcmc-c-_amd/sharded.py).  vars[n][Nchains][Nvars], stat[n][3 Nchains] = [logL | logPrior |
+ * logPost], moved[n][Nchains]; attempted / chain0 / Pswitch / switched [n]; last_* = state after the block's last sample,
+ * sum_* = sums over the block (for the *_mean entries of the restore files).  Writes the block and the restore files. */
+int tamcmc_outputs_push_block(tamcmc_outputs *o, int64_t n, const double *vars, const double *stat, const uint8_t *moved,
+                              const uint8_t *attempted, const int32_t *chain0, const double *Pswitch, const uint8_t *switched,
+                              const double *last_vars, const double *last_sigma, const double *last_mu, const double *last_covar,
+                              const double *sum_vars, const double *sum_sigma, const double *sum_mu, const double *sum_covar);
 /* Flush what is buffered and write the restore files from the sampler's current state. */
 int tamcmc_outputs_finish(tamcmc_outputs *o, const tamcmc_sampler *s);
 int tamcmc_outputs_destroy(tamcmc_outputs *o);

@@ -109,6 +109,7 @@ int tamcmc_sampler_set_iteration(tamcmc_sampler *s, int64_t iteration);
 int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s);
 int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s);
 int32_t tamcmc_sampler_nlocal(const tamcmc_sampler *s);   /* chains owned by this process */
+int tamcmc_sampler_layout(const tamcmc_sampler *s, int32_t *Nchains, int32_t *chain_offset, int32_t *Nchains_local);
 int tamcmc_sampler_destroy(tamcmc_sampler *s);
 
 /* N1 entry points, exported for tests (known answers of stats_dictionary.cpp:252-326). */

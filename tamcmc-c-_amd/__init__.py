@@ -11,9 +11,10 @@ Contents (only what the hot path needs):
   sampler.py       binding of include/tamcmc_sampler.h (priors, adaptive Metropolis + parallel tempering)
   setup_io.py      binding of include/tamcmc_io.h (.model / .data / .cfg / .list readers)
   outputs.py       binding of include/tamcmc_outputs.h (result / restore files, phase driver) + readers
+  sharded.py       one phase with the chains sharded over processes (one per GPU), files written by rank 0
   synth.py         synthetic spectra / chain parameters of SURVEY.md section 8d
 """
-from . import capi, synth, model_def, shard, sampler, setup_io, outputs  # noqa: F401
+from . import capi, synth, model_def, shard, sampler, setup_io, outputs, sharded  # noqa: F401
 from .capi import Accel, AccelError, load_library, library_path  # noqa: F401
 from .model_def import ModelDef, Data  # noqa: F401
 

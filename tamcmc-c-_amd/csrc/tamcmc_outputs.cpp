@@ -268,12 +268,10 @@ void flush_block(tamcmc_outputs &o)
     o.Ncopy++;
 }
 
-void write_restore(tamcmc_outputs &o, const tamcmc_sampler *s, long block_count)
+void write_restore_arrays(tamcmc_outputs &o, const dvec &vars, const dvec &sigma, const dvec &mu, const dvec &covar, long block_count)
 {
     const size_t nc = (size_t)o.Nchains, nv = (size_t)o.Nvars;
     const int P = o.restore_precision;
-    dvec vars = sampler_get(s, 0, nc * nv), sigma = sampler_get(s, 6, nc), mu = sampler_get(s, 7, nc * nv),
-         covar = sampler_get(s, 8, nc * nv * nv);
     const double inv = block_count > 0 ? 1.0 / (double)block_count : 0.0;
     auto mean_of = [&](const dvec &sum, const dvec &last) {
         dvec m(sum.size());
@@ -323,6 +321,13 @@ void write_restore(tamcmc_outputs &o, const tamcmc_sampler *s, long block_count)
         f << "! covarmats_mean= \n";
         for (size_t c = 0; c < nc; c++) { f << "*" << c << "\n"; rows(f, covar_m, nv, nv, c * nv * nv); }
     }
+}
+
+void write_restore(tamcmc_outputs &o, const tamcmc_sampler *s, long block_count)
+{
+    const size_t nc = (size_t)o.Nchains, nv = (size_t)o.Nvars;
+    write_restore_arrays(o, sampler_get(s, 0, nc * nv), sampler_get(s, 6, nc), sampler_get(s, 7, nc * nv), sampler_get(s, 8, nc * nv * nv),
+                         block_count);
 }
 
 void reset_sums(tamcmc_outputs &o)
@@ -451,6 +456,34 @@ extern "C" int tamcmc_outputs_finish(tamcmc_outputs *o, const tamcmc_sampler *s)
     });
 }
 
+// A whole block at once, from arrays that cover ALL chains (sharded runs: rank 0 gathers the ranks' blocks).
+extern "C" int tamcmc_outputs_push_block(tamcmc_outputs *o, int64_t n, const double *vars, const double *stat, const uint8_t *moved,
+                                         const uint8_t *attempted, const int32_t *chain0, const double *Pswitch, const uint8_t *switched,
+                                         const double *last_vars, const double *last_sigma, const double *last_mu, const double *last_covar,
+                                         const double *sum_vars, const double *sum_sigma, const double *sum_mu, const double *sum_covar)
+{
+    if (!o || n < 1 || !vars || !stat || !moved || !attempted || !chain0 || !Pswitch || !switched || !last_vars || !last_sigma ||
+        !last_mu || !last_covar || !sum_vars || !sum_sigma || !sum_mu || !sum_covar) return TAMCMC_IO_E_INVALID;
+    return guarded(&o->error, [&] {
+        const size_t nc = (size_t)o->Nchains, nv = (size_t)o->Nvars;
+        if (o->counts != 0 || (size_t)n > o->b_attempt.size()) throw Fail{TAMCMC_IO_E_INVALID, "push_block: block larger than Nbuffer, or a partial block is pending"};
+        memcpy(o->b_vars.data(), vars, (size_t)n * nc * nv * sizeof(double));
+        memcpy(o->b_stat.data(), stat, (size_t)n * 3 * nc * sizeof(double));
+        memcpy(o->b_moved.data(), moved, (size_t)n * nc);
+        memcpy(o->b_attempt.data(), attempted, (size_t)n);
+        memcpy(o->b_chain0.data(), chain0, (size_t)n * sizeof(int32_t));
+        memcpy(o->b_Pswitch.data(), Pswitch, (size_t)n * sizeof(double));
+        memcpy(o->b_switched.data(), switched, (size_t)n);
+        o->sum_vars.assign(sum_vars, sum_vars + nc * nv); o->sum_sigma.assign(sum_sigma, sum_sigma + nc);
+        o->sum_mu.assign(sum_mu, sum_mu + nc * nv); o->sum_covar.assign(sum_covar, sum_covar + nc * nv * nv);
+        o->counts = (long)n;
+        write_restore_arrays(*o, dvec(last_vars, last_vars + nc * nv), dvec(last_sigma, last_sigma + nc), dvec(last_mu, last_mu + nc * nv),
+                             dvec(last_covar, last_covar + nc * nv * nv), (long)n);
+        flush_block(*o);
+        reset_sums(*o);
+    });
+}
+
 // ---------------------------------------------------------------- Config::read_restore_files, config.cpp:1322-1577
 namespace {
 
@@ -571,15 +604,18 @@ extern "C" int tamcmc_restore_apply(const tamcmc_setup *setup, tamcmc_sampler *s
         const std::string root = trim(cfg_get(setup, "Outputs", "restore_dir")) + trim(cfg_get(setup, "Outputs", "restore_file_in", "restore_"));
         Restored R = read_restore(root, r_prop);
         const int nv = tamcmc_sampler_nvars(s);
-        const int nchains = tamcmc_sampler_nlocal(s);
+        int32_t Nglobal = 0, off = 0, nloc = 0;
+        tamcmc_sampler_layout(s, &Nglobal, &off, &nloc);
         if (R.Nvars != nv) throw Fail{TAMCMC_IO_E_SYNTAX, "Inconsistency in the number of variables between the model and the restore files"};
-        if (R.Nchains != nchains) throw Fail{TAMCMC_IO_E_SYNTAX, "Inconsistency in the number of chains between the configuration and the restore files"};
-        if (r_vars && tamcmc_sampler_set(s, 0, R.vars.data(), (int64_t)R.vars.size()) != TAMCMC_OK)
+        if (R.Nchains != Nglobal) throw Fail{TAMCMC_IO_E_SYNTAX, "Inconsistency in the number of chains between the configuration and the restore files"};
+        // a sharded process restores its own block of chains [off, off + nloc)
+        const size_t o1 = (size_t)off * nv, n1 = (size_t)nloc * nv, o2 = (size_t)off * nv * nv, n2 = (size_t)nloc * nv * nv;
+        if (r_vars && tamcmc_sampler_set(s, 0, R.vars.data() + o1, (int64_t)n1) != TAMCMC_OK)
             throw Fail{TAMCMC_IO_E_INVALID, "could not set the restored variables"};
         if (r_prop) {
             const dvec &sg = r_mean ? R.sigma_mean : R.sigma, &mu = r_mean ? R.mu_mean : R.mu, &cv = r_mean ? R.covar_mean : R.covar;
-            if (tamcmc_sampler_set(s, 6, sg.data(), (int64_t)sg.size()) != TAMCMC_OK || tamcmc_sampler_set(s, 7, mu.data(), (int64_t)mu.size()) != TAMCMC_OK ||
-                tamcmc_sampler_set(s, 8, cv.data(), (int64_t)cv.size()) != TAMCMC_OK)
+            if (tamcmc_sampler_set(s, 6, sg.data() + off, (int64_t)nloc) != TAMCMC_OK || tamcmc_sampler_set(s, 7, mu.data() + o1, (int64_t)n1) != TAMCMC_OK ||
+                tamcmc_sampler_set(s, 8, cv.data() + o2, (int64_t)n2) != TAMCMC_OK)
                 throw Fail{TAMCMC_IO_E_INVALID, "could not set the restored proposal"};
         }
         if (r_index) {

@@ -541,6 +541,14 @@ extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; return TAMC
 extern "C" int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s) { return s ? s->iter : -1; }
 extern "C" int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->Nvars : -1; }
 extern "C" int32_t tamcmc_sampler_nlocal(const tamcmc_sampler *s) { return s ? s->nloc : -1; }
+extern "C" int tamcmc_sampler_layout(const tamcmc_sampler *s, int32_t *Nchains, int32_t *chain_offset, int32_t *Nchains_local)
+{
+    if (!s) return TAMCMC_E_INVALID;
+    if (Nchains) *Nchains = s->cfg.Nchains;
+    if (chain_offset) *chain_offset = s->cfg.chain_offset;
+    if (Nchains_local) *Nchains_local = s->nloc;
+    return TAMCMC_OK;
+}
 
 // model_def.cpp:139-143 + :358-367 for the starting point of every chain
 extern "C" int tamcmc_sampler_init(tamcmc_sampler *s)

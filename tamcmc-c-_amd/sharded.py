@@ -1,0 +1,135 @@
+"""One phase of MALA::execute (MALA.cpp:608-720) with the tempered chains sharded over processes, one process per
+GPU: rank g owns the contiguous block [g n, (g+1) n) of the temperature ladder, evaluates it on its own
+device, and the only exchange step is the parallel-tempering attempt on a pair that straddles two ranks (one record
+each way between neighbours; RCCL on GPUs, gloo in the CPU tests).  Every rank consumes the whole random stream, so the
+chains -- and therefore the files rank 0 writes -- are the ones a single process would have produced."""
+import ctypes as C
+
+import numpy as np
+
+from . import outputs as O
+from . import sampler as S
+from .setup_io import IO_OK, SetupError
+
+
+def _gather(dist, arr, rank, world, device):
+    """All ranks' equally shaped float64 arrays, stacked on rank 0 ([world, ...]); None elsewhere."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    if rank != 0:
+        return None
+    return np.stack([o.cpu().numpy() for o in out])
+
+
+def run_phase_sharded(setup, evaluator, dist, rank, world, seed, device=None, restore_precision=6, progress=None):
+    """Restore (if configured) -> init -> iterate to Outputs.Nsamples; rank 0 writes the result and restore files.
+    `evaluator`: this rank's Accel (or a callable for CPU tests).  Returns the local Sampler (state after the run)."""
+    lib = O._lib()
+    cfg = setup.sampler_cfg(seed=seed)
+    N = int(cfg.Nchains)
+    if N % world != 0:
+        raise ValueError(f"Nchains={N} must be a multiple of the number of processes ({world})")
+    nloc = N // world
+    cfg.chain_offset, cfg.Nchains_local = rank * nloc, nloc
+    smp = S.Sampler(cfg, evaluator, setup.plength, setup.inputs, setup.relax, setup.err, setup.priors_names_switch,
+                    setup.priors, setup.extra_priors)
+    it0 = O.restore_apply(setup, smp)
+    smp.init()
+    nv = smp.Nvars
+    Nsamples, Nbuffer = int(setup.get("Outputs", "Nsamples")), int(setup.get("Outputs", "Nbuffer"))
+    out = C.c_void_p()
+    if rank == 0:
+        T_all = float(cfg.lambda_temp) ** np.arange(N)
+        rc = lib.tamcmc_outputs_create(C.byref(out), setup._h, N, T_all.ctypes.data_as(C.POINTER(C.c_double)), it0, int(restore_precision))
+        if rc != IO_OK:
+            raise SetupError(rc, "tamcmc_outputs_create", "see stderr")
+    lib.tamcmc_outputs_push_block.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 15
+    cap = min(Nbuffer, max(1, Nsamples - it0))
+    b_vars, b_stat, b_moved = np.empty((cap, nloc, nv)), np.empty((cap, 3, nloc)), np.empty((cap, nloc))
+    b_pt = np.empty((cap, 4))                      # attempted, chain A, Pswitch (nan = not an owner), switched (-1 = unknown)
+    sums = [np.zeros(nloc), np.zeros((nloc, nv)), np.zeros((nloc, nv, nv)), np.zeros((nloc, nv))]   # sigma, mu, covar, vars
+    k = 0
+    Pswap_last, swapped_last = 0.0, 0
+
+    def flush(n):
+        nonlocal Pswap_last, swapped_last
+        g_vars = _gather(dist, b_vars[:n], rank, world, device)
+        g_stat = _gather(dist, b_stat[:n], rank, world, device)
+        g_moved = _gather(dist, b_moved[:n], rank, world, device)
+        g_pt = _gather(dist, b_pt[:n], rank, world, device)
+        last = [_gather(dist, smp.get(w), rank, world, device) for w in ("vars", "sigma", "mu", "covarmat")]
+        g_sums = [_gather(dist, s_, rank, world, device) for s_ in sums]
+        for s_ in sums:
+            s_[...] = 0.0
+        if rank != 0:
+            return
+        vars_all = np.ascontiguousarray(np.concatenate(list(g_vars), axis=1))                     # [n, N, nv]
+        stat_all = np.ascontiguousarray(np.concatenate(list(g_stat), axis=2).reshape(n, 3 * N))   # [n, logL | logPrior | logPost]
+        moved_all = np.ascontiguousarray(np.concatenate(list(g_moved), axis=1) != 0, dtype=np.uint8)
+        att = np.ascontiguousarray(g_pt[0][:, 0] != 0, dtype=np.uint8)
+        chain0 = np.ascontiguousarray(g_pt[0][:, 1], dtype=np.int32)
+        Psw, sw = np.empty(n), np.empty(n, dtype=np.uint8)
+        for i in range(n):                                     # outcome known to the owner(s) of the pair
+            if att[i]:
+                r = np.array([g[i, 2] for g in g_pt]); s2 = np.array([g[i, 3] for g in g_pt])
+                Pswap_last, swapped_last = float(np.nanmax(r)), int(s2.max())
+            Psw[i], sw[i] = Pswap_last, swapped_last          # Model_def::Pswap / ::swaped keep their last values
+        cat = lambda g: np.ascontiguousarray(np.concatenate(list(g), axis=0))     # noqa: E731
+        l_vars, l_sigma, l_mu, l_cov = (cat(x) for x in last)
+        s_sigma, s_mu, s_cov, s_vars = (cat(x) for x in g_sums)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)                                # noqa: E731
+        rc = lib.tamcmc_outputs_push_block(out, n, ptr(vars_all), ptr(stat_all), ptr(moved_all), ptr(att), ptr(chain0), ptr(Psw), ptr(sw),
+                                           ptr(l_vars), ptr(l_sigma), ptr(l_mu), ptr(l_cov), ptr(s_vars), ptr(s_sigma), ptr(s_mu), ptr(s_cov))
+        if rc != IO_OK:
+            raise SetupError(rc, "tamcmc_outputs_push_block", lib.tamcmc_outputs_error(out).decode(errors="replace"))
+
+    import torch
+    for i in range(smp.iteration(), Nsamples):
+        if progress is not None and rank == 0 and i % Nbuffer == 0:
+            progress(i, Nsamples)
+        smp.mh_step()
+        att, A, r, sw = 0.0, -1.0, np.nan, -1.0
+        if smp.pt_due():
+            A, u = smp.pt_draw()                          # same values on every rank (replicated random stream)
+            att = 1.0
+            rA, rB = A // nloc, (A + 1) // nloc
+            if rA == rB:
+                if rank == rA:
+                    s2, r = smp.pt_local(A, u)
+                    sw = float(s2)
+            elif rank in (rA, rB):
+                send = torch.from_numpy(smp.pt_export(A if rank == rA else A + 1))
+                if device is not None:
+                    send = send.to(device)
+                recv = torch.empty_like(send)
+                peer = rB if rank == rA else rA
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]):
+                    req.wait()
+                s2, r = smp.pt_import(A, u, recv.cpu().numpy())
+                sw = float(s2)
+        b_vars[k] = smp.get("vars")
+        b_stat[k, 0], b_stat[k, 1], b_stat[k, 2] = smp.get("logL"), smp.get("logPrior"), smp.get("logPost")
+        b_moved[k] = smp._moved() if hasattr(smp, "_moved") else _moved(smp)
+        b_pt[k] = (att, A, r, sw)
+        for s_, w in zip(sums, ("sigma", "mu", "covarmat", "vars")):
+            s_ += smp.get(w)
+        k += 1
+        smp.end_iteration()
+        if k == cap or i == Nsamples - 1:
+            flush(k)
+            k = 0
+    if rank == 0:
+        if progress is not None:
+            progress(Nsamples, Nsamples)
+        lib.tamcmc_outputs_destroy(out)
+    return smp
+
+
+def _moved(smp):
+    out = np.empty(smp.nloc)
+    smp._check(smp._lib.tamcmc_sampler_get(smp._h, 10, out.ctypes.data_as(C.POINTER(C.c_double)), out.size), "tamcmc_sampler_get")
+    return out

@@ -221,7 +221,7 @@ def test_exports_match_header(accel_mod):
     import re
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tamcmc_outputs.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(tamcmc_[a-z_]+)\s*\(", txt)) - {"tamcmc_progress_fn"})
-    assert len(names) == 7
+    assert len(names) == 8
     lib = accel_mod.load_library()
     for n in names:
         assert hasattr(lib, n), n
