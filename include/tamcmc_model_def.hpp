@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "tamcmc_accel.h"
+#include "tamcmc_sampler.h"
 
 namespace tamcmc {
 
@@ -47,6 +48,23 @@ public:
     int model_fct_name_switch = 0, likelihood_fct_name_switch = 0;
     double likelihood_params = 1.0;
     std::function<long double(const double *params_row)> prior_fct;   // call_prior hook (host side)
+
+    // call_prior as the reference defines it (model_def.cpp:322-356 -> priors_calc.cpp): prior_fct_name_switch from
+    // priors_ctrl.list, the primitive-prior ids and the 4 x Nparams prior table of Input_Data, extra_priors[4]
+    void use_reference_priors(int prior_fct_name_switch, const std::vector<int32_t> &priors_names_switch,
+                              const std::vector<double> &priors /* 4 x Nparams, row-major */, const std::vector<double> &extra_priors)
+    {
+        if ((long)priors_names_switch.size() != Nparams || (long)priors.size() != 4 * Nparams || extra_priors.size() != 4)
+            throw std::runtime_error("use_reference_priors: table sizes do not match Nparams");
+        auto sw = priors_names_switch; auto pp = priors; auto ex = extra_priors; auto pl = plength;
+        const int np = (int)Nparams;
+        prior_fct = [sw, pp, ex, pl, np, prior_fct_name_switch](const double *row) -> long double {
+            int32_t err = 0;
+            const double v = tamcmc_log_prior(prior_fct_name_switch, np, row, pl.data(), sw.data(), pp.data(), 4, ex.data(), &err);
+            if (err) throw std::runtime_error("tamcmc_log_prior: invalid prior configuration");
+            return v;
+        };
+    }
 
     // Model_def(Config*, VectorXd Tcoefs, bool) -- model_def.cpp:27-181
     Model_def(const Data &data, int model_case, const std::vector<int32_t> &plength_, const std::vector<double> &inputs,

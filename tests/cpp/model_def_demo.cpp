@@ -41,6 +41,15 @@ int main()
         std::printf("grad0");
         for (long k = 0; k < md.Nvars; k++) std::printf(" %.17g", md.gradLogLikelihood[k]);
         std::printf("\nmodel0 %.17g %.17g\n", md.model[0], md.model[Nx - 1]);
+        // the reference's own prior function (priors_ctrl.list id 1 = priors_Harvey_Gaussian): Uniform, Jeffreys,
+        // Gaussian on the first three parameters, the rest Fix (primepriors_ctrl.list ids 1, 4, 2, 0)
+        const std::vector<int32_t> sw = {1, 4, 2, 0, 0, 0, 0};
+        std::vector<double> pp(4 * 7, -9999.0);
+        pp[0 * 7 + 0] = 0.0;   pp[1 * 7 + 0] = 20.0;      // Uniform(0, 20)
+        pp[0 * 7 + 1] = 10.0;  pp[1 * 7 + 1] = 1000.0;    // Jeffreys(10, 1000)
+        pp[0 * 7 + 2] = 2100.; pp[1 * 7 + 2] = 50.0;      // Gaussian(2100, 50)
+        md.use_reference_priors(1, sw, pp, {0.0, 0.0, 0.0, 0.0});
+        for (long m = 0; m < md.Nmodels; m++) std::printf("refprior %ld %.17g\n", m, (double)md.call_prior(&d, (int)m));
     } catch (const std::runtime_error &e) {
         std::printf("NODEVICE %s\n", e.what());
         return 3;

@@ -56,5 +56,12 @@ def test_cpp_adapter_matches_oracle(accel_mod, orc):
     g = np.array([float(v) for v in out["grad0"][0]])
     gfd, _ = orc.grad_fd(1, plength, x, y, P[0], T[0], idx.astype(np.int32))
     assert np.max(np.abs(g - gfd)) <= 2e-5 * np.max(np.abs(gfd))
+    from tamcmc_amd import sampler as S
+    sw = [1, 4, 2, 0, 0, 0, 0]
+    pp = np.full((4, 7), -9999.0)
+    pp[:2, 0], pp[:2, 1], pp[:2, 2] = (0.0, 20.0), (10.0, 1000.0), (2100.0, 50.0)
+    want = [S.log_prior(1, P[m], plength, sw, pp, [0, 0, 0, 0])[0] for m in range(3)]
+    got = [float(v[1]) for v in out["refprior"]]
+    assert np.allclose(got, want, rtol=1e-15) and np.all(np.isfinite(got)) and len(set(got)) == 3
     m0 = [float(v) for v in out["model0"][0]]
     assert m0[0] == pytest.approx(rm[0, 0], rel=1e-12) and m0[1] == pytest.approx(rm[0, -1], rel=1e-12)
