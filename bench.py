@@ -153,7 +153,7 @@ def main():
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "kernel_ms": round(k_avg_s * 1e3, 4), "launches": int(k_n),
         "binding_roof": "fp64 VALU, not HBM (SURVEY.md F6): x/y are shared by all chains through L2, so measured HBM "
-                        "traffic is ~10x below the algorithmic bytes; see 'valu' for the fraction of fp64 issue slots used",
+                        "traffic (FETCH_SIZE doubled per the gfx950 calibration, + WRITE_SIZE) is ~4x below the algorithmic bytes; see 'valu' for the fraction of fp64 issue slots used",
         "valu": valu,
         "logL_only": {"achieved": round(bytes_per_launch / kl_avg_s / 1e9, 2),
                       "frac": round(bytes_per_launch / kl_avg_s / 1e9 / HBM_PEAK_GBS, 5),

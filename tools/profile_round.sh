@@ -16,6 +16,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fe
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1 && echo "pmc write ok"
 # clock probe: long kernels (4096 chains) so that GRBM_GUI_ACTIVE / 8 / duration is a meaningful clock estimate
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_clock -- python3 $R/bench.py --steps 3 --warmup 1 --chains 4096 --no-cpu-baseline > $O/pmc_clock.log 2>&1 && echo "pmc clock ok"
+# FETCH_SIZE / WRITE_SIZE calibration for 8-byte-per-lane streaming accesses (MI355X_MICROARCH.md: other widths are uncalibrated)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/fetch_calib.hip -o $O/fetch_calib 2> /dev/null && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -- $O/fetch_calib > $O/calib_fetch.log 2>&1 && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib_write -- $O/fetch_calib > $O/calib_write.log 2>&1 && echo "calibration ok"; rm -f $O/fetch_calib
 cd $R && python tools/summarize_profiles.py $O
 # rehearsal of the N>1 bench path on this one GPU: 2 ranks over gloo, both on cuda:0
 cd $R && timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline --backend gloo --single-device > $O/bench_2rank_gloo_rehearsal.json 2> $O/bench_2rank.err; echo "2-rank rehearsal rc=$?"; cat $O/bench_2rank_gloo_rehearsal.json

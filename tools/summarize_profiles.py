@@ -38,11 +38,13 @@ def main(out_dir):
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 clock.setdefault(k, []).append(float(r["Counter_Value"]) / 8.0 / dur)   # cycles per ns = GHz
     out = {"kernels": res, "clock_GHz_long_kernels": {k: sum(v) / len(v) for k, v in clock.items()},
-           "note": "FETCH_SIZE/WRITE_SIZE are in KB (x1024 for bytes); 8-byte-per-lane loads are not calibrated for the "
-                   "gfx950 half-count effect of MI355X_MICROARCH.md, so read traffic is a lower bound up to 2x"}
+           "note": "FETCH_SIZE/WRITE_SIZE are in KB (x1024 for bytes).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
+                   "reports half the bytes of coalesced streaming reads; calibrated for this code's 8-byte-per-lane loads with "
+                   "tools/fetch_calib.hip (ratio 0.50001, profiles/r01e/fetch_calibration.txt), WRITE_SIZE exact (1.0): "
+                   "hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) x 1024"}
     for k, d in res.items():
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
-            d["hbm_bytes_per_launch"] = (d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+            d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
     json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     # the condensed file bench.py reads for roofline.traffic / roofline.valu
     def pick(suffix):
