@@ -95,6 +95,12 @@ int tamcmc_eval_batch_device(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams,
                              const double *d_params, const double *d_Tcoefs,
                              double *d_logL, double *d_grad, int32_t *d_status);
 
+/* tamcmc_eval_batch split in two for callers that have host work to overlap with the GPU (the sampler draws the next
+ * iteration's random numbers meanwhile): _begin copies params / Tcoefs and enqueues the likelihood evaluation, _end
+ * waits and delivers logL / status.  Likelihood only (no gradient, no model rows); one batch in flight per ctx. */
+int tamcmc_eval_batch_begin(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs);
+int tamcmc_eval_batch_end(tamcmc_ctx *ctx, int32_t Nchains, double *logL, int32_t *status);
+
 /* Replaces: Model_def::call_model_explicit (model_def.cpp:199-208) as used by tools/getmodel.cpp:111.
  * One params row -> model spectrum (Nx doubles, host).  *status gets the TAMCMC_CHAIN_* code. */
 int tamcmc_model_explicit(tamcmc_ctx *ctx, int32_t Nparams, const double *params,

@@ -18,6 +18,7 @@ CHAIN_OK, CHAIN_NAN, CHAIN_EMPTY_WINDOW = 0, 1, 2
 
 EXPORTS = [
     "tamcmc_ctx_create", "tamcmc_ctx_set_vars", "tamcmc_eval_batch", "tamcmc_eval_batch_device",
+    "tamcmc_eval_batch_begin", "tamcmc_eval_batch_end",
     "tamcmc_model_explicit", "tamcmc_ctx_set_stream", "tamcmc_ctx_synchronize", "tamcmc_ctx_profile",
     "tamcmc_ctx_kernel_time", "tamcmc_ctx_geometry", "tamcmc_ctx_destroy", "tamcmc_device_count",
     "tamcmc_strerror", "tamcmc_last_hip_error", "tamcmc_version",

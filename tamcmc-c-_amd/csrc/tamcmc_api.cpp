@@ -66,6 +66,7 @@ struct tamcmc_ctx {
     int32_t *h_status = nullptr;
     int h_cap = 0, h_nvars = -1;
     hipEvent_t ev_done = nullptr;  // completion of a host-pointer call, polled (see wait_done)
+    int in_flight = 0;             // chains of a tamcmc_eval_batch_begin not yet collected by _end
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
@@ -477,6 +478,63 @@ static int wait_done(tamcmc_ctx *c)
     }
 }
 
+// pinned, device-mapped staging of the host-pointer entry points
+static int ensure_staging(tamcmc_ctx *c, int Nchains)
+{
+    const int Nparams = c->L.Nparams;
+    if (Nchains <= c->h_cap && c->h_nvars == c->Nvars) return TAMCMC_OK;
+    TM_HIP(hipStreamSynchronize(c->stream));
+    (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
+    c->h_in = c->h_out = nullptr; c->h_status = nullptr; c->h_cap = 0;
+    const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+    const size_t cap = (size_t)(Nchains > c->cap ? Nchains : c->cap);
+    TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), cap * ((size_t)Nparams + 1) * sizeof(double), flags));
+    TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_out), cap * ((size_t)(c->Nvars > 0 ? c->Nvars : 0) + 1) * sizeof(double), flags));
+    TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_status), cap * sizeof(int32_t), flags));
+    c->h_cap = (int)cap; c->h_nvars = c->Nvars;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_eval_batch_begin(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs)
+{
+    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, Nchains, false);
+    if (rc != TAMCMC_OK) return rc;
+    rc = ensure_staging(c, Nchains);
+    if (rc != TAMCMC_OK) return rc;
+    const size_t n = (size_t)Nchains;
+    std::memcpy(c->h_in, params, n * Nparams * sizeof(double));
+    std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
+    double *dv_in = nullptr, *dv_out = nullptr;
+    int32_t *dv_status = nullptr;
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_in), c->h_in, 0));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_out), c->h_out, 0));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_status), c->h_status, 0));
+    rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, nullptr, dv_status, nullptr, nullptr);
+    if (rc != TAMCMC_OK) return rc;
+    if (!c->ev_done) TM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    TM_HIP(hipEventRecord(c->ev_done, c->stream));
+    c->in_flight = Nchains;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_eval_batch_end(tamcmc_ctx *c, int32_t Nchains, double *logL, int32_t *status)
+{
+    if (!c || !logL || c->in_flight != Nchains) return TAMCMC_E_INVALID;
+    c->in_flight = 0;
+    for (;;) {
+        const hipError_t e = hipEventQuery(c->ev_done);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e)); return TAMCMC_E_HIP; }
+        __builtin_ia32_pause();
+    }
+    TM_HIP(hipGetLastError());
+    std::memcpy(logL, c->h_out, (size_t)Nchains * sizeof(double));
+    if (status) std::memcpy(status, c->h_status, (size_t)Nchains * sizeof(int32_t));
+    return TAMCMC_OK;
+}
+
 extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams,
                                  const double *params, const double *Tcoefs,
                                  double *logL, double *grad,
@@ -494,17 +552,9 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     if (rc != TAMCMC_OK) return rc;
 
     const size_t n = (size_t)Nchains;
-    if (Nchains > c->h_cap || c->h_nvars != c->Nvars) {
-        TM_HIP(hipStreamSynchronize(c->stream));
-        (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
-        c->h_in = c->h_out = nullptr; c->h_status = nullptr; c->h_cap = 0;
-        const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
-        const size_t cap = (size_t)(Nchains > c->cap ? Nchains : c->cap);
-        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), cap * ((size_t)Nparams + 1) * sizeof(double), flags));
-        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_out), cap * ((size_t)(c->Nvars > 0 ? c->Nvars : 0) + 1) * sizeof(double), flags));
-        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_status), cap * sizeof(int32_t), flags));
-        c->h_cap = (int)cap; c->h_nvars = c->Nvars;
-    }
+    if (c->in_flight) return TAMCMC_E_INVALID;
+    rc = ensure_staging(c, Nchains);
+    if (rc != TAMCMC_OK) return rc;
     std::memcpy(c->h_in, params, n * Nparams * sizeof(double));
     std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
     double *dv_in = nullptr, *dv_out = nullptr;

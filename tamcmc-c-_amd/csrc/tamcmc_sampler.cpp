@@ -451,9 +451,17 @@ struct tamcmc_sampler {
     std::vector<double> covar, sigma, mu, Lchol;
     std::vector<uint8_t> chol_valid;
     // scratch
-    std::vector<double> p_prop, v_prop, L_prop, u_mh, z, z_all, chol_scratch;
+    std::vector<double> p_prop, v_prop, L_prop, u_mh, u_now, z, z_all, chol_scratch;
     std::vector<int32_t> status;
     std::vector<Rng::NormalPlan> plans;          // one per local chain (+1 for chains owned elsewhere)
+    // The random numbers of an iteration do not depend on any outcome, so they are drawn one iteration ahead, while the
+    // GPU evaluates the current proposals: MH draws of iteration i+1 (and the parallel-tempering draws of iteration i,
+    // which precede them in the stream) are consumed right after the evaluation of iteration i was launched.
+    bool drawn_ahead = false;                    // plans / u_mh / z_all already hold the draws of the coming mh_step
+    bool pt_cached = false;                      // parallel-tempering draws of the current iteration already consumed
+    int32_t pt_A = 0;
+    double pt_u = 0.0;
+    tamcmc_ctx *hip_ctx = nullptr;               // set by create_hip: the evaluation can be split in begin / end
     std::unique_ptr<ChainPool> pool;
     Rng rng;
     int64_t iter = 0;
@@ -534,7 +542,9 @@ extern "C" int tamcmc_sampler_create_hip(tamcmc_sampler **out, const tamcmc_samp
                                          const int32_t *sw, const double *pp, int32_t nrows, const double extra[4], const double *err)
 {
     if (!ctx) return TAMCMC_E_INVALID;
-    return sampler_alloc(out, cfg, hip_eval_trampoline, ctx, Nparams, plength, inputs, relax, sw, pp, nrows, extra, err);
+    const int rc = sampler_alloc(out, cfg, hip_eval_trampoline, ctx, Nparams, plength, inputs, relax, sw, pp, nrows, extra, err);
+    if (rc == TAMCMC_OK) (*out)->hip_ctx = ctx;
+    return rc;
 }
 
 extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; return TAMCMC_OK; }
@@ -610,6 +620,27 @@ static bool learning_now(const tamcmc_sampler *s, int64_t i, int64_t *period)
     return logic;
 }
 
+// MH draws of one iteration in the reference's order: for each chain, u then z (MALA.cpp:451,465,346)
+static void draw_mh(tamcmc_sampler *s)
+{
+    const int n = s->nloc, nv = s->Nvars, off = s->cfg.chain_offset;
+    for (int g = 0; g < s->cfg.Nchains; g++) {
+        const double u = s->rng.uniform();
+        const int m = g - off;
+        const bool mine = (m >= 0 && m < n);
+        s->rng.draw(nv, s->plans[mine ? (size_t)m : (size_t)n]);
+        if (mine) s->u_mh[m] = u;
+    }
+}
+
+static void draw_pt(tamcmc_sampler *s)
+{
+    s->pt_u = s->rng.uniform();                                   // MALA.cpp:384
+    s->pt_A = (int32_t)(s->rng.g.next() % (s->cfg.Nchains - 1));  // random_int_vals(0, Nchains-1), :390 and :178-187
+}
+
+extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s);
+
 extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
 {
     if (!s) return TAMCMC_E_INVALID;
@@ -618,13 +649,11 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     const double gamma = s->cfg.c0 / (1. + (double)i);             // MALA.cpp:630
     // 1. proposals.  Random draws first, in the reference's order: for each chain, u then z (MALA.cpp:451,465,346);
     //    then the per-chain linear algebra, chains in parallel.
-    for (int g = 0; g < s->cfg.Nchains; g++) {
-        const double u = s->rng.uniform();
-        const int m = g - off;
-        const bool mine = (m >= 0 && m < n);
-        s->rng.draw(nv, s->plans[mine ? (size_t)m : (size_t)n]);
-        if (mine) s->u_mh[m] = u;
+    if (!s->drawn_ahead) {
+        draw_mh(s);
+        s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
     }
+    s->drawn_ahead = false;
     std::atomic<int64_t> bad{0};
     s->pool->run(n, [&](int m) {
         if (!s->chol_valid[m]) {
@@ -636,8 +665,7 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
             if (!cholesky(tmp, nv, &s->Lchol[(size_t)m * nv * nv], tmp + (size_t)nv * nv)) bad.fetch_add(1, std::memory_order_relaxed);
             s->chol_valid[m] = 1;
         }
-        double *z = &s->z_all[(size_t)m * nv];
-        s->plans[m].fill(z);
+        const double *z = &s->z_all[(size_t)m * nv];
         const double *Lc = &s->Lchol[(size_t)m * nv * nv];
         for (int a = 0; a < nv; a++) {
             double acc = 0.0;
@@ -648,8 +676,23 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
     });
     s->bad_chol += bad.load();
-    // 2. the hot path: every local chain in one call
-    int rc = s->eval(s->eval_user, n, np, s->p_prop.data(), &s->T[off], s->L_prop.data(), s->status.data());
+    // 2. the hot path: every local chain in one call.  While the GPU works, consume the stream one iteration ahead:
+    //    the parallel-tempering draws of THIS iteration (MALA.cpp:384,390; they come first in the stream), then the
+    //    MH draws of the next one and their Box-Muller transforms.  u_mh of this iteration is kept aside first.
+    int rc;
+    if (s->hip_ctx) {
+        rc = tamcmc_eval_batch_begin(s->hip_ctx, n, np, s->p_prop.data(), &s->T[off]);
+        if (rc != TAMCMC_OK) return rc;
+        s->u_now = s->u_mh;
+        if (tamcmc_sampler_pt_due(s) && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
+        draw_mh(s);
+        s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+        s->drawn_ahead = true;
+        rc = tamcmc_eval_batch_end(s->hip_ctx, n, s->L_prop.data(), s->status.data());
+    } else {
+        s->u_now = s->u_mh;
+        rc = s->eval(s->eval_user, n, np, s->p_prop.data(), &s->T[off], s->L_prop.data(), s->status.data());
+    }
     if (rc != TAMCMC_OK) return rc;
     // 3. accept / reject and adaptation, MALA.cpp:475-534, :641-652
     int64_t period = 1;
@@ -667,7 +710,7 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         } else {
             r = 0.;
         }
-        if (s->u_mh[m] <= r) {
+        if (s->u_now[m] <= r) {
             std::memcpy(&s->params[(size_t)m * np], &s->p_prop[(size_t)m * np], sizeof(double) * np);
             std::memcpy(&s->vars[(size_t)m * nv], &s->v_prop[(size_t)m * nv], sizeof(double) * nv);
             s->logL[m] = s->L_prop[m]; s->logPrior[m] = lpr; s->logPost[m] = lpo;
@@ -691,8 +734,10 @@ extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s)
 extern "C" int tamcmc_sampler_pt_draw(tamcmc_sampler *s, int32_t *A, double *u)
 {
     if (!s || !A || !u) return TAMCMC_E_INVALID;
-    *u = s->rng.uniform();                                   // MALA.cpp:384
-    *A = (int32_t)(s->rng.g.next() % (s->cfg.Nchains - 1));  // random_int_vals(0, Nchains-1), :390 and :178-187
+    if (!s->pt_cached) draw_pt(s);          // (already consumed during the evaluation when drawing ahead)
+    s->pt_cached = false;
+    *u = s->pt_u;
+    *A = s->pt_A;
     return TAMCMC_OK;
 }
 
