@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_artefacts():
+    """The built library / tools / oracle normally travel with the tree; build them if a checkout lacks them."""
+    import subprocess
+    need = [os.path.join(ROOT, "tamcmc-c-_amd", "libtamcmc_accel.so"), os.path.join(ROOT, "bin", "cpptamcmc_hip"),
+            os.path.join(ROOT, "bin", "getmodel_hip")]
+    if not all(os.path.exists(f) for f in need):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tamcmc-c-_amd", "csrc"), "-j4"], check=True)
+    if not any(f.endswith(".so") for f in os.listdir(os.path.join(ROOT, "oracle"))):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
 @pytest.fixture(scope="session")
 def orc():
     """CPU oracle (test infrastructure)."""
