@@ -36,7 +36,8 @@ __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + 
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
 #define TM_BW_THREADS 256
-__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int UB, int units,
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int ub_shift, int tq, int trem,
+                                                             unsigned long long magic_q, unsigned long long magic_q1,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmChain *__restrict__ chain_rec,
@@ -118,9 +119,11 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         double acc = 0.0;
         if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
             // tiles whose sub-block range [TM_TILE_U0(t), TM_TILE_U0(t+1)) meets the window's sub-blocks [ua, ub]
-            const int ua = M.imin / UB, ub = (M.imax - 1) / UB;
-            const int tq = units / tiles, trem = units % tiles;
-            int t0 = (ua < trem * (tq + 1)) ? ua / (tq + 1) : trem + (ua - trem * (tq + 1)) / tq;
+            // (UB is a power of two; the two quotients use host-made reciprocals: exact for operands < 2^20)
+            const int ua = M.imin >> ub_shift, ub = (M.imax - 1) >> ub_shift;
+            const int rest = ua - trem * (tq + 1);
+            int t0 = (rest < 0) ? (int)(((unsigned long long)ua * magic_q1) >> 40)
+                                : trem + (int)(((unsigned long long)rest * magic_q) >> 40);
             if (t0 > tiles - 1) t0 = tiles - 1;
             for (int t = t0; t < tiles && TM_TILE_U0Q(t, tq, trem) <= ub; t++)
                 acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
@@ -427,8 +430,13 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    int ub_shift = 0;
+    while ((1 << ub_shift) < unit_bins) ub_shift++;
+    if ((1 << ub_shift) != unit_bins || tiles < 1 || units < tiles || units >= (1 << 20)) return (int)hipErrorInvalidValue;
+    const int tq = units / tiles, trem = units % tiles;
+    const unsigned long long magic_q = ((1ULL << 40) + tq - 1) / tq, magic_q1 = ((1ULL << 40) + tq) / (tq + 1);
     hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
-                       unit_bins, units, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
+                       ub_shift, tq, trem, magic_q, magic_q1, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
                        static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, Nvars,
                        d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();

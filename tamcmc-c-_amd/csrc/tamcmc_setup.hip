@@ -23,6 +23,8 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
     extern __shared__ double s_p[];   // this chain's params row: every later access is an LDS read
     double *p = s_p;
     for (int e = tid; e < L.Nparams; e += TM_SETUP_THREADS) p[e] = params[(size_t)chain * L.Nparams + e];
+    // the caller's temperature array may live in host memory: read it once, now (latency hidden behind the work below)
+    const double Tc = (tid == 64) ? Tcoefs[chain] : 1.0;
     __shared__ TmChain C;
     __shared__ TmMultFull s_M[64];    // per-lane scratchpad: dynamically indexed fields stay out of scratch memory
     __shared__ int s_status;
@@ -157,8 +159,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
 #endif
     if (tid == 64) {
         s_N.status = s_status;
-        const double Tc = Tcoefs[chain];     // the caller's array may live in host memory: read once, keep a device copy
-        wt[2 * chain] = Tc;
+        wt[2 * chain] = Tc;                  // device copy for the eval / backward kernels
         wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
         noise[chain] = s_N;
     }
