@@ -62,10 +62,68 @@ __device__ __forceinline__ double tm_rcp(double x)
     return r;
 }
 
-__device__ __forceinline__ double tm_wave_sum(double v)
+// ---- lane exchanges without LDS traffic -----------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 (two per double, through the LDS crossbar); the reductions of the gradient
+// pass issue ~50 of them per multiplet and wave and were bound by that path (profiles/README.md).  gfx950 has
+// v_permlane32_swap / v_permlane16_swap for the two wide steps, and DPP covers masks 1..8 (semantics checked on the
+// hardware with tools/xor_exchange_probe.hip).
+template <int MASK>
+__device__ __forceinline__ unsigned tm_xor_dw(unsigned v, int lane)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if constexpr (MASK == 1) return __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4) {
+        const unsigned r = __builtin_amdgcn_update_dpp(0u, v, 0x104, 0xf, 0x5, false);                // row_shl:4 -> banks 0, 2
+        return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);                             // row_shr:4 -> banks 1, 3
+    } else if constexpr (MASK == 8) return __builtin_amdgcn_update_dpp(0u, v, 0x128, 0xf, 0xf, false); // row_ror:8
+    else if constexpr (MASK == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+
+template <int MASK>
+__device__ __forceinline__ double tm_xor(double v, int lane)   // the value lane ^ MASK holds
+{
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = tm_xor_dw<MASK>((unsigned)b, lane), hi = tm_xor_dw<MASK>((unsigned)(b >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// One butterfly step on a PAIR of values with the two-register swaps: returns, in lanes with the MASK bit clear,
+// a[lane] + a[lane ^ MASK], and in lanes with the bit set, b[lane ^ MASK] + b[lane]  (MASK = 16 or 32 only).
+template <int MASK>
+__device__ __forceinline__ double tm_swap_add(double a, double b)
+{
+    static_assert(MASK == 16 || MASK == 32, "two-register swaps exist for 16 and 32 lanes");
+    const unsigned long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    unsigned r0l, r1l, r0h, r1h;
+    if constexpr (MASK == 32) {
+        const auto l = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+        r0l = l[0]; r1l = l[1]; r0h = h[0]; r1h = h[1];
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+        r0l = l[0]; r1l = l[1]; r0h = h[0]; r1h = h[1];
+    }
+    const double r0 = __longlong_as_double(((unsigned long long)r0h << 32) | r0l);
+    const double r1 = __longlong_as_double(((unsigned long long)r1h << 32) | r1l);
+    return r0 + r1;
+}
+
+__device__ __forceinline__ double tm_wave_sum(double v)   // lane 0 ends with the same tree as the shfl_down form
+{
+    const int lane = threadIdx.x & 63;
+    v += tm_xor<32>(v, lane);
+    v += tm_xor<16>(v, lane);
+    v += tm_xor<8>(v, lane);
+    v += tm_xor<4>(v, lane);
+    v += tm_xor<2>(v, lane);
+    v += tm_xor<1>(v, lane);
     return v;
 }
 
@@ -104,7 +162,10 @@ struct TmBfly {
     __device__ static __forceinline__ void run(double (&v)[TM_GSLOTS], int lane)
     {
         if constexpr (N == 1) {
-            v[0] += __shfl_xor(v[0], MASK, 64);
+            v[0] += tm_xor<MASK>(v[0], lane);
+        } else if constexpr (MASK >= 16) {
+#pragma unroll
+            for (int i = 0; i < H; i++) v[i] = tm_swap_add<MASK>(v[i], (i + H < N) ? v[i + H] : 0.0);
         } else {
             const bool hi = (lane & MASK) != 0;
 #pragma unroll
@@ -112,7 +173,7 @@ struct TmBfly {
                 const double up = (i + H < N) ? v[i + H] : 0.0;
                 const double send = hi ? v[i] : up;
                 const double keep = hi ? up : v[i];
-                v[i] = keep + __shfl_xor(send, MASK, 64);
+                v[i] = keep + tm_xor<MASK>(send, lane);
             }
         }
         if constexpr (MASK > 1) TmBfly<(N == 1 ? 1 : H), MASK / 2>::run(v, lane);
