@@ -326,6 +326,12 @@ __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restric
     }
 }
 
+#ifndef TM_UG_FWD
+#define TM_UG_FWD 1     // sub-blocks per multiplet-loop group, likelihood kernel (KU = 4: already 4 chains per record fetch)
+#endif
+#ifndef TM_UG_GRAD
+#define TM_UG_GRAD 2    // gradient kernel (KU = 2): 4 bins per record fetch
+#endif
 #ifndef TM_LB_FWD
 #define TM_LB_FWD 4    // resident waves per SIMD the register allocator must allow (likelihood-only kernel)
 #endif
@@ -395,38 +401,53 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     for (int s_ = 0; s_ < (GRAD ? TM_GSLOTS : 1); s_++) gn_[s_] = 0.0;
     const double wscale = GRAD ? a.wt[2 * chain + 1] : 0.0;
 
+    // The multiplet loop runs on UG sub-blocks at a time (UG * KU bins per thread): a multiplet's record is fetched
+    // (scalar loads) once per group, and UG * KU independent rational chains are in flight; background, likelihood
+    // and the gradient weights are then done sub-block by sub-block as before.
+    constexpr int UG = GRAD ? TM_UG_GRAD : TM_UG_FWD, KG = UG * KU;
 #pragma unroll 1
-    for (int u = 0; u < S; u++) {
-        double x2[KU], acc[KU], wreg[GRAD ? KU : 1];
-        int bi[KU];
+    for (int ug = 0; ug < S; ug += UG) {
+        double x2g[KG], accg[KG];
+        int big[KG];
 #pragma unroll
-        for (int k = 0; k < KU; k++) {
-            const int i = base + (u * KU + k) * TM_THREADS + tid;
-            const bool valid = i < a.Nx;
-            bi[k] = valid ? i : -1;
-            x2[k] = 2.0 * a.x[valid ? i : a.Nx - 1];
-            acc[k] = 0.0;
+        for (int k = 0; k < KG; k++) {
+            const int i = base + (ug * KU + k) * TM_THREADS + tid;
+            const bool valid = (i < a.Nx) && (ug + k / KU < S);
+            big[k] = valid ? i : -1;
+            x2g[k] = 2.0 * a.x[(i < a.Nx) ? i : a.Nx - 1];
+            accg[k] = 0.0;
         }
-        for (int jj = 0; jj < nact; jj++) {
-            TmMultK sm = (TmMultK)(gm + tix[jj]);
-            const int lo = base + u * KU * TM_THREADS;
-            if (lo + KU * TM_THREADS <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
-            if (sm->has_asym) {
-                switch (sm->ncomp) {
-                case 1: tm_accum_mult<1, KU, true>(sm, x2, bi, acc); break;
-                case 3: tm_accum_mult<3, KU, true>(sm, x2, bi, acc); break;
-                case 5: tm_accum_mult<5, KU, true>(sm, x2, bi, acc); break;
-                default: tm_accum_mult<7, KU, true>(sm, x2, bi, acc); break;
-                }
-            } else {
-                switch (sm->ncomp) {
-                case 1: tm_accum_mult<1, KU, false>(sm, x2, bi, acc); break;
-                case 3: tm_accum_mult<3, KU, false>(sm, x2, bi, acc); break;
-                case 5: tm_accum_mult<5, KU, false>(sm, x2, bi, acc); break;
-                default: tm_accum_mult<7, KU, false>(sm, x2, bi, acc); break;
+        {
+            const int lo = base + ug * KU * TM_THREADS;
+            const int hi = lo + ((ug + UG <= S) ? KG : (S - ug) * KU) * TM_THREADS;
+            for (int jj = 0; jj < nact; jj++) {
+                TmMultK sm = (TmMultK)(gm + tix[jj]);
+                if (hi <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
+                if (sm->has_asym) {
+                    switch (sm->ncomp) {
+                    case 1: tm_accum_mult<1, KG, true>(sm, x2g, big, accg); break;
+                    case 3: tm_accum_mult<3, KG, true>(sm, x2g, big, accg); break;
+                    case 5: tm_accum_mult<5, KG, true>(sm, x2g, big, accg); break;
+                    default: tm_accum_mult<7, KG, true>(sm, x2g, big, accg); break;
+                    }
+                } else {
+                    switch (sm->ncomp) {
+                    case 1: tm_accum_mult<1, KG, false>(sm, x2g, big, accg); break;
+                    case 3: tm_accum_mult<3, KG, false>(sm, x2g, big, accg); break;
+                    case 5: tm_accum_mult<5, KG, false>(sm, x2g, big, accg); break;
+                    default: tm_accum_mult<7, KG, false>(sm, x2g, big, accg); break;
+                    }
                 }
             }
         }
+#pragma unroll
+      for (int uu = 0; uu < UG; uu++) {
+        const int u = ug + uu;
+        if (u >= S) break;
+        double x2[KU], acc[KU], wreg[GRAD ? KU : 1];
+        int bi[KU];
+#pragma unroll
+        for (int k = 0; k < KU; k++) { x2[k] = x2g[uu * KU + k]; acc[k] = accg[uu * KU + k]; bi[k] = big[uu * KU + k]; }
         double hu[TM_MAXH][GRAD ? KU : 1], harg[GRAD ? KU : 1];   // GRAD: u = 1/(1+t) per Harvey and bin (t u = 1 - u), log x per bin
         bool n0_done = false;
         if (nh > 0) {
@@ -559,6 +580,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 }
             }
         }
+      }   // sub-blocks of the group
     }
     TM_STAMP(1);
     double S2 = 0.0;
