@@ -703,6 +703,9 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 default: tm_grad_mult<7, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
                 }
             }
+#if defined(TM_ABLATE) && (TM_ABLATE & 64)   // timing-only build: no workgroup barrier per multiplet (wave 0 publishes its own partial)
+            if (tid < TM_GSLOTS) a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + tix[jj]) * TM_GSLOTS + tid] = red[tid];
+#else
             __syncthreads();
             if (tid < TM_GSLOTS) {
                 double t = 0.0;
@@ -712,6 +715,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
                 }
                 a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + tix[jj]) * TM_GSLOTS + tid] = t;
             }
+#endif
         }
     }
 }
