@@ -49,7 +49,7 @@ struct tamcmc_ctx {
     int cap = 0;
     bool cap_grad = false;
     double *d_params = nullptr, *d_T = nullptr, *d_logL = nullptr, *d_part = nullptr;
-    double *d_gmult = nullptr, *d_gnoise = nullptr, *d_grad = nullptr;
+    double *d_gmult = nullptr, *d_gnoise = nullptr, *d_grad = nullptr, *d_hser = nullptr;
     int32_t *d_status = nullptr, *d_rows = nullptr;
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
@@ -162,13 +162,13 @@ static int build_layout(TmLayout &L, int model_case, int likelihood_case, double
 static void free_batch(tamcmc_ctx *c)
 {
     (void)hipFree(c->d_params); (void)hipFree(c->d_T); (void)hipFree(c->d_logL); (void)hipFree(c->d_part);
-    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad);
+    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad); (void)hipFree(c->d_hser);
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
     (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
     (void)hipFree(c->d_ticket); c->d_ticket = nullptr;
     (void)hipFree(c->d_wt); c->d_wt = nullptr;
-    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = nullptr;
+    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = c->d_hser = nullptr;
     c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
     c->cap = 0; c->cap_grad = false;
 }
@@ -198,6 +198,7 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     if (g) {
         TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g_cap * nm * TM_GSLOTS * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g_cap * TM_NSLOTS * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_hser, n * c->tiles_g_cap * TM_MAXH * TM_HSER * sizeof(double)));
         const int nv = c->Nvars > 0 ? c->Nvars : 1;
         TM_HIP(hipMalloc(&c->d_grad, n * nv * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_chain_rec, n * tm_sizeof_chain_rec()));
@@ -406,7 +407,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int tiles = pick_tiles(c, Nchains, grad);
     if (!grad) c->last_tiles = tiles;
     int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, tiles, c->d_mult, c->d_noise, c->d_trec,
-                             c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, c->stream);
+                             c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
@@ -437,7 +438,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
         rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K, units, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
-                                c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->Nvars, c->d_relax, d_grad, d_logL,
+                                c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->d_trec, c->d_hser, c->Nvars, c->d_relax, d_grad, d_logL,
                                 d_status, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }

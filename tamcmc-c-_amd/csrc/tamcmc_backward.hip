@@ -46,6 +46,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                                                              const double *__restrict__ part,
                                                              const double *__restrict__ gmult,
                                                              const double *__restrict__ gnoise,
+                                                             const TmTileRec *__restrict__ trec, const double *__restrict__ hser,
                                                              int Nvars, const int32_t *__restrict__ relax,
                                                              double *__restrict__ grad,
                                                              double *__restrict__ logL, int32_t *__restrict__ status,
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     extern __shared__ double s_dyn[];
     __shared__ TmChain C;
     __shared__ double s_gn[TM_NSLOTS];
+    __shared__ double s_gt[TM_NSLOTS][64 + 1];   // per-lane noise partials of wave 1 (padded: conflict-free column reads)
     __shared__ double s_S[TM_NSHARED];
     const int nm = L.n_mult;
     // dynamic LDS carve-up: the chain's params row first (every later access is an LDS read)
@@ -82,12 +84,66 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     if (L.family != TM_FAM_GAUSS)
         for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_BW_THREADS)
             reinterpret_cast<double *>(&C)[e] = reinterpret_cast<const double *>(chain_rec + chain)[e];
-    // noise partials: one lane per slot, tiles in order (independent loads, pipelined)
-    if (tid >= 64 && tid < 64 + TM_NSLOTS) {
-        const int sl = tid - 64;
-        double acc = 0.0;
-        for (int t = 0; t < tiles; t++) acc += gnoise[((size_t)chain * tiles + t) * TM_NSLOTS + sl];
-        s_gn[sl] = acc;
+    // noise partials: wave 1, one lane per tile (stride 64).  On a tile whose background was evaluated as a polynomial
+    // the eval kernel left the moments m_j = sum w dl^j (slot 9: j = 0, slot j-1: j = 1..9); with profile h's series
+    // u_h = sum c_j dl^j (setup kernel) and u(1-u) = -(1/p) du/d(dl) = sum d_j dl^j, d_j = -(j+1) c_{j+1}/p:
+    //   sum w u = sum c_j m_j,  sum w u(1-u) = sum d_j m_j,  sum w u(1-u)(lt + log x) = (lt + lxc) sum d_j m_j + sum d_j m_{j+1}.
+    // Other tiles hold those three sums already.  Lanes then meet in LDS and are summed in a fixed order.
+    if (tid >= 64 && tid < 128) {
+        const int lane = tid - 64;
+        double acc[TM_NSLOTS];
+#pragma unroll
+        for (int sl = 0; sl < TM_NSLOTS; sl++) acc[sl] = 0.0;
+        const TmNoise *nz = noise + chain;
+        const int nh = nz->nh;
+        for (int t = lane; t < tiles; t += 64) {
+            const double *G = gnoise + ((size_t)chain * tiles + t) * TM_NSLOTS;
+            double g[TM_NSLOTS];
+#pragma unroll
+            for (int sl = 0; sl < TM_NSLOTS; sl++) g[sl] = G[sl];
+            const TmTileRec *R = trec + (size_t)chain * tiles + t;
+            if (nh > 0 && R->npoly != 0) {
+                double m[TM_HSER];
+                m[0] = g[3 * TM_MAXH];
+#pragma unroll
+                for (int j = 1; j < TM_HSER; j++) m[j] = g[j - 1];
+#pragma unroll
+                for (int sl = 0; sl < 3 * TM_MAXH; sl++) g[sl] = 0.0;
+                const double lxc = R->lxc;
+#pragma unroll
+                for (int h = 0; h < TM_MAXH; h++) {
+                    if (h < nh) {
+                        const double *c = hser + (((size_t)chain * tiles + t) * TM_MAXH + h) * TM_HSER;
+                        const double ip = -1.0 / nz->p[h];
+                        double k0 = 0.0, k1 = 0.0, k2 = 0.0;
+#pragma unroll
+                        for (int j = TM_PDEG; j >= 0; j--) {
+                            const double dj = (double)(j + 1) * c[j + 1] * ip;
+                            k0 = __builtin_fma(c[j], m[j], k0);
+                            k1 = __builtin_fma(dj, m[j], k1);
+                            k2 = __builtin_fma(dj, m[j + 1], k2);
+                        }
+                        g[3 * h] = k0;
+                        g[3 * h + 1] = k1;
+                        g[3 * h + 2] = __builtin_fma(nz->lt[h] + lxc, k1, k2);
+                    }
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < TM_NSLOTS; sl++) acc[sl] += g[sl];
+        }
+        // lane l -> LDS; then lane l sums slot l/4 over lanes (l%4)*16 .. +15, and the four parts are added in a tree
+#pragma unroll
+        for (int sl = 0; sl < TM_NSLOTS; sl++) s_gt[sl][lane] = acc[sl];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int sl = lane >> 2, part = lane & 3;
+        double tsum = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) tsum += s_gt[sl][part * 16 + e];
+        tsum += __shfl_xor(tsum, 1, 64);
+        tsum += __shfl_xor(tsum, 2, 64);
+        if (part == 0) s_gn[sl] = tsum;
     }
     // finalize (same arithmetic and order as the likelihood-only path's in-launch finalize): wave 3
     if (tid >= 192) {
@@ -413,6 +469,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins, int units, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise,
+                       const TmTileRec *d_trec, const double *d_hser,
                        int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
                        void *stream)
 {
@@ -437,7 +494,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins,
     const unsigned long long magic_q = ((1ULL << 40) + tq - 1) / tq, magic_q1 = ((1ULL << 40) + tq) / (tq + 1);
     hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
                        ub_shift, tq, trem, magic_q, magic_q1, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
-                       static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, Nvars,
+                       static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, d_trec, d_hser, Nvars,
                        d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();
 }

@@ -7,6 +7,7 @@
 //   noise[Nchains]          : TmNoise -- Harvey / white-noise / Gaussian terms per chain
 //   part[Nchains][tiles][2] : per-tile partial sums of the likelihood (fixed-order reduction)
 //   gmult[Nchains][tiles][n_mult][TM_GSLOTS], gnoise[Nchains][tiles][TM_NSLOTS] : gradient partials
+//   hser[Nchains][tiles][TM_MAXH][TM_HSER] : per-profile series of u = 1/(1+t) in (log x - lxc), gradient path only
 //   logL[Nchains], status[Nchains] (int32), grad[Nchains][Nvars]
 #pragma once
 #include <stdint.h>
@@ -18,6 +19,7 @@
 #define TM_GSLOTS 24   // gradient partials per (tile, multiplet): 3 per component + 3 asymmetry sums
 #define TM_NSLOTS 16   // gradient partials per tile for the noise terms: 3 per Harvey + N0 (+pad)
 #define TM_PDEG 8      // degree of the in-tile Taylor polynomials of the Harvey profiles
+#define TM_HSER 10     // per-profile series coefficients kept for the gradient path (degree TM_PDEG + 1: one more for the derivative)
 
 // model families (how the params row is unpacked)
 #define TM_FAM_GAUSS  0  // ids 0, 1          models.cpp:1968-2034
@@ -116,7 +118,7 @@ struct ihipStream_t;
 // unit_bins / units / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
                     int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
-                    void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, void *stream);
+                    void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, double *d_hser /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
@@ -124,7 +126,7 @@ int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *st
 int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins, int units, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise,
-                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
+                       const TmTileRec *d_trec, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
                        void *stream);
 }
 #endif

@@ -457,26 +457,12 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             if (npoly) {
 #pragma unroll
                 for (int k = 0; k < KU; k++) dl[k] -= lxc;
-                if constexpr (GRAD) {
-                    // each profile's u is needed on its own for the noise partial sums
+                // whole background (all profiles + white noise) as ONE polynomial: 8 FMAs per bin.  The gradient path
+                // accumulates the moments sum w dl^j instead of per-profile sums (below); the backward kernel turns
+                // them into the per-profile sums with each profile's own series coefficients.
 #pragma unroll
-                    for (int h = 0; h < TM_MAXH; h++) {
-                        if (h < nh) {
-                            const double Hh = sn->H[h], ph = sn->p[h], t0 = tr->t0[h];
-#pragma unroll
-                            for (int k = 0; k < KU; k++) {
-                                const double t = t0 * tm_exp_small(ph * dl[k]);   // t0 < 1e290: no overflow
-                                hu[h][k] = tm_rcp(t + 1.0);
-                                acc[k] = __builtin_fma(Hh, hu[h][k], acc[k]);
-                            }
-                        }
-                    }
-                } else {
-                    // whole background (all profiles + white noise) as ONE polynomial: 8 FMAs per bin
-#pragma unroll
-                    for (int k = 0; k < KU; k++) acc[k] += tm_poly(tr, dl[k]);
-                    n0_done = true;
-                }
+                for (int k = 0; k < KU; k++) { acc[k] += tm_poly(tr, dl[k]); if constexpr (GRAD) harg[k] = dl[k]; }
+                n0_done = true;
             } else {
 #pragma unroll
                 for (int h = 0; h < TM_MAXH; h++) {
@@ -558,7 +544,12 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             for (int k = 0; k < KU; k++) {
                 const double wk = wreg[k];
                 gn_[3 * TM_MAXH] += wk;
-                if (nh > 0) {
+                if (nh > 0 && npoly) {
+                    // moments of the weights about the tile centre: slot j-1 <- sum w dl^j, j = 1..TM_HSER-1
+                    double q = wk;
+#pragma unroll
+                    for (int j = 0; j < TM_HSER - 1; j++) { q *= harg[k]; gn_[j] += q; }
+                } else if (nh > 0) {
 #pragma unroll
                     for (int h = 0; h < TM_MAXH; h++) {
                         if (h < nh) {

@@ -15,7 +15,8 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
                                                           const double *__restrict__ lx, int UB, int units, int tiles,
                                                           TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
                                                           TmTileRec *__restrict__ trec, int32_t *__restrict__ tidx,
-                                                          TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux)
+                                                          TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
+                                                          double *__restrict__ hser)
 {
     __shared__ int s_win[TM_MAXMULT][2];   // truncation windows, for the per-tile active lists
     const int chain = blockIdx.x;
@@ -101,24 +102,28 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
                     const double t0 = exp(ph * (s_N.lt[h] + lx_c));
                     ok = ok && (t0 < 1e290);
                     R.t0[h] = t0;
-                    const double ifac[TM_PDEG + 1] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320};
-                    double d[TM_PDEG + 1], u[TM_PDEG + 1];
+                    // one degree more than the model polynomial uses: the gradient path differentiates the series
+                    const double ifac[TM_HSER] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880};
+                    double d[TM_HSER], u[TM_HSER];
                     d[0] = 1.0 + t0;
 #pragma unroll
-                    for (int j = 1; j <= TM_PDEG; j++) d[j] = t0 * ifac[j];
+                    for (int j = 1; j < TM_HSER; j++) d[j] = t0 * ifac[j];
                     const double id0 = 1.0 / d[0];
                     u[0] = id0;
 #pragma unroll
-                    for (int j = 1; j <= TM_PDEG; j++) {
+                    for (int j = 1; j < TM_HSER; j++) {
                         double acc = 0.0;
 #pragma unroll
                         for (int i = 1; i <= j; i++) acc = acc + d[i] * u[j - i];
                         u[j] = -id0 * acc;
                     }
                     double pj = 1.0;
+                    double *hs = (hser != nullptr) ? hser + (((size_t)chain * tiles + tile) * TM_MAXH + h) * TM_HSER : nullptr;
 #pragma unroll
-                    for (int j = 0; j <= TM_PDEG; j++) {
-                        R.bg[j] = R.bg[j] + Hh * (u[j] * pj);   // coefficient of (log x - lxc)^j
+                    for (int j = 0; j < TM_HSER; j++) {
+                        const double cj = u[j] * pj;                 // coefficient of (log x - lxc)^j in u_h
+                        if (j <= TM_PDEG) R.bg[j] = R.bg[j] + Hh * cj;
+                        if (hs != nullptr) hs[j] = cj;
                         pj = pj * ph;
                     }
                 }
@@ -179,11 +184,11 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
                     int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
-                    void *d_chain_rec, void *d_aux, void *stream)
+                    void *d_chain_rec, void *d_aux, double *d_hser, void *stream)
 {
     hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
                        d_params, d_Tcoefs, d_wt, d_lx, unit_bins, units, tiles, d_mult, d_noise, d_trec, d_tidx,
-                       static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux));
+                       static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux), d_hser);
     return (int)hipGetLastError();
 }
 
