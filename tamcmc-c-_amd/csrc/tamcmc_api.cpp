@@ -246,6 +246,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_S_GRAD", 1, 16, &c->Sg);
     env_int("TAMCMC_TILES", 1, 1 << 20, &c->force_tiles);
     env_int("TAMCMC_TILES_GRAD", 1, 1 << 20, &c->force_tiles_g);
+    { int v = 0; env_int("TAMCMC_BG_EXACT", 0, 1, &v); c->L.bg_exact = v; }
     if (c->K == 3) c->K = 4;
     if (c->Kg == 3) c->Kg = 2;
     {

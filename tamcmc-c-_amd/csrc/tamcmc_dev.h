@@ -40,7 +40,7 @@ struct TmLayout {
     int32_t nharvey;      // Harvey profiles evaluated (0 for local models, models.cpp:1818)
     int32_t likelihood_case;
     int32_t Nx;
-    int32_t pad;
+    int32_t bg_exact;     // developer switch (env TAMCMC_BG_EXACT=1): no in-tile polynomials, exp() per bin and profile
     double  x0, xlast, step;  // x[0], x[Nx-1], x[1]-x[0] (models.cpp:489)
     double  like_p;           // (double)(long)likelihood_params
 };

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
             int i1 = base + TB - 1; if (i1 > L.Nx - 1) i1 = L.Nx - 1;
             const double lx_c = lx[ic], lx_0 = lx[base], lx_1 = lx[i1];
             const double span = fmax(fabs(lx_0 - lx_c), fabs(lx_1 - lx_c));
-            bool ok = (span == span) && (lx_c - lx_c == 0.0);
+            bool ok = (span == span) && (lx_c - lx_c == 0.0) && (L.bg_exact == 0);
             R.lxc = lx_c;
 #pragma unroll
             for (int j = 0; j <= TM_PDEG; j++) R.bg[j] = 0.0;

@@ -75,6 +75,34 @@ def test_gradient_full_size_is_reproducible(accel_mod, orc):
     assert np.allclose(g1[3] * T[3], g1[3] * T[3])
 
 
+def test_gradient_on_polynomial_background_tiles(accel_mod, orc, monkeypatch):
+    """On the C2 grid (2300-3140 uHz) every tile evaluates the Harvey background as a polynomial in log x and the
+    gradient kernel keeps moments of the weights instead of per-profile sums (tamcmc_backward.hip converts them).
+    (a) finite differences of the oracle on a short piece of that grid, all variables incl. the 10 noise parameters;
+    (b) full size: same logL and gradient as the exp()-per-bin path (developer switch TAMCMC_BG_EXACT=1)."""
+    w = synth.workload_c2(Nx=6000, trunc_c=10000.0)
+    m, _ = orc.model(2, w["params_true"], w["plength"], w["x"])
+    fd_check(accel_mod, orc, 2, w, synth.make_spectrum(m, seed=31))
+
+    w = synth.workload_c2()
+    m, _ = orc.model(2, w["params_true"], w["plength"], w["x"])
+    y = synth.make_spectrum(m)
+    P = synth.chain_params(w, 6)
+    T = synth.temperatures(6)
+    out = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("TAMCMC_BG_EXACT", exact)
+        with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+            acc.set_vars(w["index_to_relax"])
+            out.append(acc.eval_batch(P, T, grad=True))
+    (L0, s0, g0), (L1, s1, g1) = out
+    assert np.all(s0 == 0) and np.all(s1 == 0)
+    assert np.allclose(L0, L1, rtol=1e-13, atol=0)
+    scale = np.max(np.abs(g1), axis=1, keepdims=True)
+    assert np.max(np.abs(g0 - g1) / scale) < 1e-11
+    assert not np.array_equal(g0, g1)      # the two paths really are different code
+
+
 def test_gradient_requires_vars(accel_mod, orc):
     w = W.make(2, Nx=1000)
     y = np.ones(1000)
