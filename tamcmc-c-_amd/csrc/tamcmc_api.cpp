@@ -33,7 +33,7 @@ struct tamcmc_ctx {
     TmLayout L{};
     // Tile geometry.  The grid is cut into `units` sub-blocks of 256*KU bins, spread over T = ceil(units / S) tiles
     // (sizes differ by at most one sub-block); S / Sg bound the tile size (Sg also bounds the LDS of pass 2).
-    int K = 4, S = 2;              // likelihood only: KU bins in flight per thread, at most S sub-blocks (2048 bins) per tile
+    int K = 4, S = 3;              // likelihood only: KU bins in flight per thread, at most S sub-blocks (3072 bins) per tile
     int Kg = 2, Sg = 7;            // with gradient partials: 2 bins in flight, at most 7 sub-blocks (3584 bins, 28 KB of LDS)
     int units = 0, units_g = 0;    // sub-blocks in the grid at K / Kg
     int tiles_cap = 0, tiles_g_cap = 0;   // largest T pick_tiles may return (buffers are sized for it)
@@ -50,6 +50,7 @@ struct tamcmc_ctx {
     bool cap_grad = false;
     double *d_params = nullptr, *d_T = nullptr, *d_logL = nullptr, *d_part = nullptr;
     double *d_gmult = nullptr, *d_gnoise = nullptr, *d_grad = nullptr, *d_hser = nullptr;
+    int32_t *d_order = nullptr; int order_mode = 2;
     int32_t *d_status = nullptr, *d_rows = nullptr;
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
@@ -162,7 +163,7 @@ static int build_layout(TmLayout &L, int model_case, int likelihood_case, double
 static void free_batch(tamcmc_ctx *c)
 {
     (void)hipFree(c->d_params); (void)hipFree(c->d_T); (void)hipFree(c->d_logL); (void)hipFree(c->d_part);
-    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad); (void)hipFree(c->d_hser);
+    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad); (void)hipFree(c->d_hser); (void)hipFree(c->d_order); c->d_order = nullptr;
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
     (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
@@ -195,6 +196,7 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMemset(c->d_ticket, 0, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_trec, n * c->tiles_max * sizeof(TmTileRec)));
     TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(int32_t)));
+    TM_HIP(hipMalloc(&c->d_order, n * c->tiles_max * sizeof(int32_t)));
     if (g) {
         TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g_cap * nm * TM_GSLOTS * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g_cap * TM_NSLOTS * sizeof(double)));
@@ -247,6 +249,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_TILES", 1, 1 << 20, &c->force_tiles);
     env_int("TAMCMC_TILES_GRAD", 1, 1 << 20, &c->force_tiles_g);
     { int v = 0; env_int("TAMCMC_BG_EXACT", 0, 1, &v); c->L.bg_exact = v; }
+    env_int("TAMCMC_ORDER", 0, 2, &c->order_mode);
     if (c->K == 3) c->K = 4;
     if (c->Kg == 3) c->Kg = 2;
     {
@@ -408,7 +411,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int tiles = pick_tiles(c, Nchains, grad);
     if (!grad) c->last_tiles = tiles;
     int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, tiles, c->d_mult, c->d_noise, c->d_trec,
-                             c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr, c->stream);
+                             c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr, c->order_mode == 2 ? c->d_order : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
@@ -418,7 +421,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
-    a.units = units;
+    a.units = units; a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0;
     a.tile_q = units / tiles; a.tile_rem = units % tiles;
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     if (c->profile) {

@@ -19,6 +19,7 @@
 #define TM_GSLOTS 24   // gradient partials per (tile, multiplet): 3 per component + 3 asymmetry sums
 #define TM_NSLOTS 16   // gradient partials per tile for the noise terms: 3 per Harvey + N0 (+pad)
 #define TM_PDEG 8      // degree of the in-tile Taylor polynomials of the Harvey profiles
+#define TM_ORDER_MAX 1024   // tile counts up to this are launched costliest-first (rank table built in LDS)
 #define TM_HSER 10     // per-profile series coefficients kept for the gradient path (degree TM_PDEG + 1: one more for the derivative)
 
 // model families (how the params row is unpacked)
@@ -99,7 +100,8 @@ struct TmEvalArgs {
     const int32_t *row_of_chain;// NULL or [Nchains]: row of model_out to fill, -1 none
     double *model_out;
     int32_t Nx, n_mult, tiles, likelihood_case;
-    int32_t units, pad;         // the grid is cut into `units` sub-blocks of 256*KU bins; tile t owns sub-blocks
+    const int32_t *order;       // [Nchains][tiles] launch rank -> tile, costliest first (setup kernel), or NULL
+    int32_t units, order_mode;  // the grid is cut into `units` sub-blocks of 256*KU bins; tile t owns sub-blocks
                                 // [TM_TILE_U0(t), TM_TILE_U0(t+1)): sizes differ by at most one sub-block
     int32_t tile_q, tile_rem;   // units / tiles, units % tiles
     double like_p;
@@ -118,7 +120,8 @@ struct ihipStream_t;
 // unit_bins / units / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
                     int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
-                    void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, double *d_hser /* may be NULL */, void *stream);
+                    void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, double *d_hser /* may be NULL */,
+                    int32_t *d_order /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);

@@ -353,12 +353,19 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     // when tiles = 1 (mod 8); a tile count that is a multiple of 8 pins each tile to one XCD and the XCD with the
     // densest tiles finishes ~15 % late (profiles/README.md).  Rotating the slot -> tile map by r * chain with
     // r = (tiles - 1) mod 8 makes (XCD - tile) = chain (mod 8) for every tile count.
-    const int chain = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int chain, tile;
+    if (a.order_mode == 0) {
+        chain = blockIdx.y;
+        const unsigned rn = (unsigned)((a.tiles - 1) & 7) * (unsigned)(chain & 0xffff);          // < 2^19
+        const unsigned rq = (unsigned)(((unsigned long long)rn * a.tile_magic) >> 40);           // rn / tiles (scalar unit)
+        tile = (int)blockIdx.x + (int)(rn - rq * (unsigned)a.tiles);
+        if (tile >= a.tiles) tile -= a.tiles;
+    } else {
+        chain = blockIdx.x;
+        tile = (a.order_mode == 2) ? a.order[(size_t)chain * a.tiles + blockIdx.y] : (int)blockIdx.y;
+    }
     TmNoiseK sn = (TmNoiseK)(a.noise + chain);
-    const unsigned rn = (unsigned)((a.tiles - 1) & 7) * (unsigned)(chain & 0xffff);          // < 2^19
-    const unsigned rq = (unsigned)(((unsigned long long)rn * a.tile_magic) >> 40);           // rn / tiles (scalar unit)
-    int tile = (int)blockIdx.x + (int)(rn - rq * (unsigned)a.tiles);
-    if (tile >= a.tiles) tile -= a.tiles;
     const int u_first = TM_TILE_U0Q(tile, a.tile_q, a.tile_rem);
     const int S = a.tile_q + (tile < a.tile_rem ? 1 : 0);             // sub-blocks of this tile
     constexpr int KU2 = (KU > 2) ? 2 : KU;   // pass 2 keeps 3 accumulators per component: fewer bins in flight
@@ -715,6 +722,7 @@ template <int KU>
 static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
 {
     dim3 grid(a.tiles, Nchains), block(TM_THREADS);
+    if (a.order_mode != 0) grid = dim3(Nchains, a.tiles);
     const int Smax = (a.units + a.tiles - 1) / a.tiles;
     size_t lds = grad ? (size_t)TM_THREADS * KU * Smax * sizeof(double) : 8;
     if (lds > 48 * 1024) {

@@ -16,9 +16,10 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
                                                           TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
                                                           TmTileRec *__restrict__ trec, int32_t *__restrict__ tidx,
                                                           TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
-                                                          double *__restrict__ hser)
+                                                          double *__restrict__ hser, int32_t *__restrict__ order)
 {
-    __shared__ int s_win[TM_MAXMULT][2];   // truncation windows, for the per-tile active lists
+    __shared__ int s_win[TM_MAXMULT][3];   // truncation windows and component counts, for the per-tile active lists
+    __shared__ __attribute__((aligned(16))) int s_cost[TM_ORDER_MAX + 4];
     const int chain = blockIdx.x;
     const int tid = threadIdx.x;
     extern __shared__ double s_p[];   // this chain's params row: every later access is an LDS read
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
                 else             { out.nu2[k] = 0.0;           out.hq[k] = 0.0; }
             }
             out.imin = M.imin; out.imax = M.imax; out.ncomp = M.ncomp;
-            s_win[j][0] = M.imin; s_win[j][1] = M.imax;
+            s_win[j][0] = M.imin; s_win[j][1] = M.imax; s_win[j][2] = M.ncomp;
             if (M.status != 0) atomicMax(&s_status, M.status);
             mult[(size_t)chain * L.n_mult + j] = out;
             if (aux != nullptr) aux[(size_t)chain * L.n_mult + j] = M;
@@ -175,20 +176,48 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
     for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) {
         const int base = TM_TILE_U0(tile, units, tiles) * UB, TB = TM_TILE_U0(tile + 1, units, tiles) * UB - base;
         int32_t *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
-        int nact = 0;
+        int nact = 0, cost = 0;
         for (int j = 0; j < nm; j++)
-            if (s_win[j][0] < base + TB && s_win[j][1] > base) ti[nact++] = j;
+            if (s_win[j][0] < base + TB && s_win[j][1] > base) {
+                ti[nact++] = j;
+                const int lo = s_win[j][0] > base ? s_win[j][0] : base, hi = s_win[j][1] < base + TB ? s_win[j][1] : base + TB;
+                cost += (s_win[j][2] + 2) * ((hi - lo + 255) >> 8);     // ~ component evaluations, in units of 256 bins
+            }
         trec[(size_t)chain * tiles + tile].nact = nact;
+        // unique key: cost first, lower tile index first among equals
+        if (tile < TM_ORDER_MAX) s_cost[tile] = ((cost < (1 << 20) ? cost : (1 << 20)) << 10) + (TM_ORDER_MAX - 1 - tile);
+    }
+    // launch order of this chain's tiles: costliest first (rank = number of tiles with a larger key)
+    if (order != nullptr) {
+        if (tiles <= TM_ORDER_MAX) {
+            if (tid < 4) s_cost[tiles + tid] = -1;            // padding for the 4-wide reads below: never "costs more"
+            __syncthreads();
+            for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) {
+                const int c = s_cost[tile];
+                int r = 0;
+#pragma unroll 4
+                for (int t2 = 0; t2 < tiles; t2 += 4) {
+                    const int4 c4 = *reinterpret_cast<const int4 *>(&s_cost[t2]);
+                    r += (c4.x > c) ? 1 : 0;
+                    r += (c4.y > c) ? 1 : 0;
+                    r += (c4.z > c) ? 1 : 0;
+                    r += (c4.w > c) ? 1 : 0;
+                }
+                order[(size_t)chain * tiles + r] = tile;
+            }
+        } else {
+            for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) order[(size_t)chain * tiles + tile] = tile;
+        }
     }
 }
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
                     int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
-                    void *d_chain_rec, void *d_aux, double *d_hser, void *stream)
+                    void *d_chain_rec, void *d_aux, double *d_hser, int32_t *d_order, void *stream)
 {
     hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
                        d_params, d_Tcoefs, d_wt, d_lx, unit_bins, units, tiles, d_mult, d_noise, d_trec, d_tidx,
-                       static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux), d_hser);
+                       static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux), d_hser, d_order);
     return (int)hipGetLastError();
 }
 
