@@ -460,7 +460,11 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
         if (nh > 0) {
             double dl[KU];
 #pragma unroll
+#if defined(TM_ABLATE) && (TM_ABLATE & 128)   // timing-only build: no log x load (wrong values)
+            for (int k = 0; k < KU; k++) { dl[k] = lxc + 1e-9 * x2[k]; if constexpr (GRAD) harg[k] = dl[k]; }
+#else
             for (int k = 0; k < KU; k++) { dl[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1]; if constexpr (GRAD) harg[k] = dl[k]; }
+#endif
             if (npoly) {
 #pragma unroll
                 for (int k = 0; k < KU; k++) dl[k] -= lxc;
