@@ -248,3 +248,44 @@ def test_large_grid_and_many_chains(accel_mod, orc):
     assert np.array_equal(st2, rst2)
     check_logL(L2, rL2)
     assert np.array_equal(L2b, L2[:3])
+
+
+def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
+    """The eval launch is tile-major and costliest-first (rank table from the setup kernel).  Results must be bitwise
+    the same for the chain-major order (TAMCMC_ORDER=0), plain tile-major (1) and ranked (2, default), and for a tile
+    count above TM_ORDER_MAX = 1024, where the rank table is the identity."""
+    w = synth.workload_c2(Nx=30000)
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 5)
+    T = synth.temperatures(5)
+    res = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("TAMCMC_ORDER", mode)
+        with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+            acc.set_vars(w["index_to_relax"])
+            L, st = acc.eval_batch(P, T)
+            Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        res.append((L, Lg, g))
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    check_logL(res[2][0], rL)
+    monkeypatch.delenv("TAMCMC_ORDER")
+
+    w = synth.workload_c2(Nx=1200000)
+    w["x"] = synth.grid(1200000, 2300.0, 840.0 / 1200000)
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 2)
+    T = synth.temperatures(2)
+    monkeypatch.setenv("TAMCMC_TILES", "1100")
+    monkeypatch.setenv("TAMCMC_TILES_GRAD", "1100")
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        assert acc.geometry()["tiles"] == 1100
+        L, st = acc.eval_batch(P, T)
+        Lg, stg, g = acc.eval_batch(P, T, grad=True)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst)
+    check_logL(L, rL)
+    check_logL(Lg, rL)
+    assert np.all(np.isfinite(g))
