@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=500)   # ~65 ms: the clocks of an idle GPU take ~50 ms of load to settle
     ap.add_argument("--chains", type=int, default=64, help="chains per GPU")
     ap.add_argument("--nx", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")

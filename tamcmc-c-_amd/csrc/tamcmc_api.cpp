@@ -31,13 +31,12 @@ static thread_local char g_hip_err[256] = "";
 struct tamcmc_ctx {
     int device = 0;
     TmLayout L{};
-    // Tile geometry.  The grid is cut into `units` sub-blocks of 256*KU bins, spread over T = ceil(units / S) tiles
-    // (sizes differ by at most one sub-block); S / Sg bound the tile size (Sg also bounds the LDS of pass 2).
-    int K = 4, S = 3;              // likelihood only: KU bins in flight per thread, at most S sub-blocks (3072 bins) per tile
-    int Kg = 2, Sg = 7;            // with gradient partials: 2 bins in flight, at most 7 sub-blocks (3584 bins, 28 KB of LDS)
+    // Tile geometry (TM_TILE_U0 in tamcmc_dev.h): the grid is cut into `units` sub-blocks of 256*KU bins; tiles alternate
+    // between S and S2 sub-blocks.  Sg also bounds the LDS of the gradient kernel's second pass (8 bytes per bin).
+    int K = 4, S = 4, S2 = 1;      // likelihood only: KU bins in flight per thread; tiles of S / S2 sub-blocks of 1024 bins
+    int Kg = 2, Sg = 8, Sg2 = 8;   // with gradient partials: 2 bins in flight; tiles of Sg / Sg2 sub-blocks of 512 bins (32 KB of LDS)
     int units = 0, units_g = 0;    // sub-blocks in the grid at K / Kg
-    int tiles_cap = 0, tiles_g_cap = 0;   // largest T pick_tiles may return (buffers are sized for it)
-    int force_tiles = 0, force_tiles_g = 0;   // developer knobs TAMCMC_TILES / TAMCMC_TILES_GRAD
+    int tiles_cap = 0, tiles_g_cap = 0;   // tiles of the two geometries (buffers are sized for them)
     int slots = 0, slots_g = 0;    // resident workgroups of the two kernels on this device
     int last_tiles = 0;            // T of the most recent likelihood-only call (tamcmc_ctx_geometry)
     int tiles_max = 0;
@@ -246,8 +245,10 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_S", 1, 64, &c->S);
     env_int("TAMCMC_KU_GRAD", 1, 4, &c->Kg);
     env_int("TAMCMC_S_GRAD", 1, 16, &c->Sg);
-    env_int("TAMCMC_TILES", 1, 1 << 20, &c->force_tiles);
-    env_int("TAMCMC_TILES_GRAD", 1, 1 << 20, &c->force_tiles_g);
+    if (getenv("TAMCMC_S")) c->S2 = c->S;                // a size given alone means uniform tiles
+    if (getenv("TAMCMC_S_GRAD")) c->Sg2 = c->Sg;
+    env_int("TAMCMC_S2", 1, 64, &c->S2);
+    env_int("TAMCMC_S2_GRAD", 1, 16, &c->Sg2);
     { int v = 0; env_int("TAMCMC_BG_EXACT", 0, 1, &v); c->L.bg_exact = v; }
     env_int("TAMCMC_ORDER", 0, 2, &c->order_mode);
     if (c->K == 3) c->K = 4;
@@ -256,15 +257,10 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
         const int64_t UB = (int64_t)TM_THREADS * c->K, UBg = (int64_t)TM_THREADS * c->Kg;
         c->units = (int)((Nx + UB - 1) / UB);
         c->units_g = (int)((Nx + UBg - 1) / UBg);
-        auto cap_of = [](int units, int Smax) {
-            const int tmin = (units + Smax - 1) / Smax;
-            int cap = 2 * tmin + 8;                      // room for finer tilings that fill whole rounds
-            return cap > units ? units : cap;
-        };
-        c->tiles_cap = cap_of(c->units, c->S);
-        c->tiles_g_cap = cap_of(c->units_g, c->Sg);
-        if (c->force_tiles > c->tiles_cap) c->tiles_cap = c->force_tiles > c->units ? c->units : c->force_tiles;
-        if (c->force_tiles_g > c->tiles_g_cap) c->tiles_g_cap = c->force_tiles_g > c->units_g ? c->units_g : c->force_tiles_g;
+        if (c->S2 > c->S) c->S2 = c->S;
+        if (c->Sg2 > c->Sg) c->Sg2 = c->Sg;
+        c->tiles_cap = tm_tile_count(c->units, c->S, c->S2);
+        c->tiles_g_cap = tm_tile_count(c->units_g, c->Sg, c->Sg2);
     }
     c->tiles_max = c->tiles_cap > c->tiles_g_cap ? c->tiles_cap : c->tiles_g_cap;
 
@@ -382,7 +378,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
 {
     if (!c) return TAMCMC_E_INVALID;
     const int T = c->last_tiles > 0 ? c->last_tiles : pick_tiles(c, 64, false);
-    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K * ((c->units + T - 1) / T);   // the largest tile
+    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K * c->S;   // the largest tile
     if (tiles) *tiles = T;
     if (threads_per_block) *threads_per_block = TM_THREADS;
     if (n_multiplets) *n_multiplets = c->L.n_mult;
@@ -393,12 +389,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
 // of chains evaluated beside it (a sharded run and a single-process run have to produce bit-identical chains).
 static int pick_tiles(const tamcmc_ctx *c, int /*Nchains*/, bool grad)
 {
-    const int units = grad ? c->units_g : c->units, Smax = grad ? c->Sg : c->S;
-    const int cap = grad ? c->tiles_g_cap : c->tiles_cap, forced = grad ? c->force_tiles_g : c->force_tiles;
-    int tmin = (units + Smax - 1) / Smax;
-    if (tmin > cap) tmin = cap;
-    if (forced > 0) return forced < tmin ? tmin : (forced > cap ? cap : forced);
-    return tmin;
+    return grad ? c->tiles_g_cap : c->tiles_cap;
 }
 
 // Enqueue setup -> eval (-> backward) for device-resident inputs.
@@ -409,8 +400,9 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int K = grad ? c->Kg : c->K;
     const int units = grad ? c->units_g : c->units;
     const int tiles = pick_tiles(c, Nchains, grad);
+    const int big = grad ? c->Sg : c->S, small = grad ? c->Sg2 : c->S2;
     if (!grad) c->last_tiles = tiles;
-    int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, tiles, c->d_mult, c->d_noise, c->d_trec,
+    int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, big, small, c->d_mult, c->d_noise, c->d_trec,
                              c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr, c->order_mode == 2 ? c->d_order : nullptr, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
@@ -422,7 +414,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
     a.units = units; a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0;
-    a.tile_q = units / tiles; a.tile_rem = units % tiles;
+    a.tile_big = big; a.tile_small = small;
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     if (c->profile) {
         while (c->ev.size() < c->ev_used + 2) {
@@ -441,7 +433,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, tiles, TM_THREADS * K, units, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
+        rc = tm_launch_backward(c->L, Nchains, TM_THREADS * K, units, big, small, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
                                 c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->d_trec, c->d_hser, c->Nvars, c->d_relax, d_grad, d_logL,
                                 d_status, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }

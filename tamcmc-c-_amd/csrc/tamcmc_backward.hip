@@ -36,8 +36,8 @@ __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + 
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
 #define TM_BW_THREADS 256
-__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int ub_shift, int tq, int trem,
-                                                             unsigned long long magic_q, unsigned long long magic_q1,
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int ub_shift, int big, int small,
+                                                             unsigned long long magic_p,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmChain *__restrict__ chain_rec,
@@ -174,14 +174,13 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const TmMultFull &M = auxp[j];
         double acc = 0.0;
         if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
-            // tiles whose sub-block range [TM_TILE_U0(t), TM_TILE_U0(t+1)) meets the window's sub-blocks [ua, ub]
-            // (UB is a power of two; the two quotients use host-made reciprocals: exact for operands < 2^20)
+            // tiles whose sub-blocks meet the window's sub-blocks [ua, ub]
+            // (UB is a power of two; the quotient uses a host-made reciprocal: exact for operands < 2^20)
             const int ua = M.imin >> ub_shift, ub = (M.imax - 1) >> ub_shift;
-            const int rest = ua - trem * (tq + 1);
-            int t0 = (rest < 0) ? (int)(((unsigned long long)ua * magic_q1) >> 40)
-                                : trem + (int)(((unsigned long long)rest * magic_q) >> 40);
+            const int pair = (int)(((unsigned long long)ua * magic_p) >> 40);      // ua / (big + small)
+            int t0 = 2 * pair + ((ua - pair * (big + small) >= big) ? 1 : 0);
             if (t0 > tiles - 1) t0 = tiles - 1;
-            for (int t = t0; t < tiles && TM_TILE_U0Q(t, tq, trem) <= ub; t++)
+            for (int t = t0; t < tiles && TM_TILE_U0(t, big, small) <= ub; t++)
                 acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
         }
         s_G[item] = acc;
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     }
 }
 
-int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins, int units, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units, int big, int small, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise,
                        const TmTileRec *d_trec, const double *d_hser,
@@ -489,11 +488,11 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins,
     }
     int ub_shift = 0;
     while ((1 << ub_shift) < unit_bins) ub_shift++;
-    if ((1 << ub_shift) != unit_bins || tiles < 1 || units < tiles || units >= (1 << 20)) return (int)hipErrorInvalidValue;
-    const int tq = units / tiles, trem = units % tiles;
-    const unsigned long long magic_q = ((1ULL << 40) + tq - 1) / tq, magic_q1 = ((1ULL << 40) + tq) / (tq + 1);
+    if ((1 << ub_shift) != unit_bins || big < 1 || small < 1 || units < 1 || units >= (1 << 20)) return (int)hipErrorInvalidValue;
+    const int tiles = tm_tile_count(units, big, small);
+    const unsigned long long magic_p = ((1ULL << 40) + (unsigned long long)(big + small) - 1) / (unsigned long long)(big + small);
     hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
-                       ub_shift, tq, trem, magic_q, magic_q1, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
+                       ub_shift, big, small, magic_p, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
                        static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, d_trec, d_hser, Nvars,
                        d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();

@@ -101,32 +101,42 @@ struct TmEvalArgs {
     double *model_out;
     int32_t Nx, n_mult, tiles, likelihood_case;
     const int32_t *order;       // [Nchains][tiles] launch rank -> tile, costliest first (setup kernel), or NULL
-    int32_t units, order_mode;  // the grid is cut into `units` sub-blocks of 256*KU bins; tile t owns sub-blocks
-                                // [TM_TILE_U0(t), TM_TILE_U0(t+1)): sizes differ by at most one sub-block
-    int32_t tile_q, tile_rem;   // units / tiles, units % tiles
+    int32_t units, order_mode;  // the grid is cut into `units` sub-blocks of 256*KU bins (see TM_TILE_U0 below)
+    int32_t tile_big, tile_small;   // sub-blocks of the even / odd tiles
     double like_p;
     unsigned long long tile_magic;   // ceil(2^40 / tiles): n / tiles == (n * tile_magic) >> 40 for n < 2^20 (slot -> tile rotation)
 };
 
-// first sub-block of tile t when `units` sub-blocks are spread over `tiles` tiles as evenly as possible: with
-// q = units / tiles and rem = units % tiles the first `rem` tiles own q + 1 sub-blocks, the others q (no division)
-#define TM_TILE_U0Q(t, q, rem) ((int)(t) * (int)(q) + ((int)(t) < (int)(rem) ? (int)(t) : (int)(rem)))
-#define TM_TILE_U0(t, units, tiles) TM_TILE_U0Q(t, (units) / (tiles), (units) % (tiles))
+// Tile geometry.  The grid is cut into `units` sub-blocks of 256*KU bins; tiles alternate between `big` and `small`
+// sub-blocks: tile 2k starts at sub-block k*(big+small) and owns `big` of them, tile 2k+1 owns the `small` ones that
+// follow; the last tile is cut at `units`.  big == small gives uniform tiles.  Two sizes exist for the sake of the
+// launch's tail: tiles are launched costliest-first, so the small ones run last and the launch ends on short
+// workgroups (profiles/README.md).  The geometry depends on the grid only, never on the batch or the parameters.
+#define TM_TILE_U0(t, big, small) ((((int)(t)) >> 1) * ((int)(big) + (int)(small)) + ((((int)(t)) & 1) ? (int)(big) : 0))
+#define TM_TILE_S(t, big, small, units)                                                                              \
+    ((((((int)(t)) & 1) ? (int)(small) : (int)(big)) < (int)(units) - TM_TILE_U0(t, big, small))                      \
+         ? ((((int)(t)) & 1) ? (int)(small) : (int)(big))                                                             \
+         : (int)(units) - TM_TILE_U0(t, big, small))
+static inline int tm_tile_count(int units, int big, int small)
+{
+    const int P = big + small, n = units / P, rem = units - n * P;
+    return 2 * n + (rem > 0 ? 1 : 0) + (rem > big ? 1 : 0);
+}
 
 #ifdef __cplusplus
 extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
-// unit_bins / units / tiles: geometry of the eval launch that follows (the tile descriptors are built for it)
+// unit_bins / units / big / small: geometry of the eval launch that follows (the tile descriptors are built for it)
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
-                    int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
+                    int units, int big, int small, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
                     void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, double *d_hser /* may be NULL */,
                     int32_t *d_order /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
-int tm_launch_backward(const TmLayout &L, int Nchains, int tiles, int unit_bins, int units, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units, int big, int small, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise,
                        const TmTileRec *d_trec, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,

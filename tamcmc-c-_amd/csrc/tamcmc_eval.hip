@@ -366,8 +366,8 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
         tile = (a.order_mode == 2) ? a.order[(size_t)chain * a.tiles + blockIdx.y] : (int)blockIdx.y;
     }
     TmNoiseK sn = (TmNoiseK)(a.noise + chain);
-    const int u_first = TM_TILE_U0Q(tile, a.tile_q, a.tile_rem);
-    const int S = a.tile_q + (tile < a.tile_rem ? 1 : 0);             // sub-blocks of this tile
+    const int u_first = TM_TILE_U0(tile, a.tile_big, a.tile_small);
+    const int S = TM_TILE_S(tile, a.tile_big, a.tile_small, a.units);   // sub-blocks of this tile
     constexpr int KU2 = (KU > 2) ? 2 : KU;   // pass 2 keeps 3 accumulators per component: fewer bins in flight
     const int Sp2 = S * (KU / KU2);          // sub-blocks of pass 2
     const int lane = tid & 63, wave = tid >> 6;
@@ -719,6 +719,7 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
             }
 #endif
         }
+        TM_STAMP(2);   // gradient kernel: slot 2 = end of pass 2
     }
 }
 
@@ -727,7 +728,7 @@ static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStre
 {
     dim3 grid(a.tiles, Nchains), block(TM_THREADS);
     if (a.order_mode != 0) grid = dim3(Nchains, a.tiles);
-    const int Smax = (a.units + a.tiles - 1) / a.tiles;
+    const int Smax = a.tile_big > a.tile_small ? a.tile_big : a.tile_small;
     size_t lds = grad ? (size_t)TM_THREADS * KU * Smax * sizeof(double) : 8;
     if (lds > 48 * 1024) {
         const void *fn = grad ? reinterpret_cast<const void *>(tamcmc_eval_kernel<KU, true>)
@@ -740,7 +741,8 @@ static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStre
     static size_t cap = 0;
     const size_t nblk = (size_t)a.tiles * Nchains;
     const char *tf = getenv("TAMCMC_TRACE_FILE");
-    if (tf && !grad) {
+    const bool trace_grad = getenv("TAMCMC_TRACE_GRAD") != nullptr;
+    if (tf && grad == trace_grad) {
         if (nblk > cap) { (void)hipFree(d_trace); (void)hipMalloc(&d_trace, nblk * 4 * sizeof(unsigned long long)); cap = nblk; }
         (void)hipMemsetAsync(d_trace, 0, nblk * 4 * sizeof(unsigned long long), stream);
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tm_trace), &d_trace, sizeof(d_trace), 0, hipMemcpyHostToDevice, stream);
@@ -749,12 +751,12 @@ static int tm_launch_eval_k(const TmEvalArgs &a, int Nchains, bool grad, hipStre
     if (grad) hipLaunchKernelGGL((tamcmc_eval_kernel<KU, true>), grid, block, lds, stream, a);
     else      hipLaunchKernelGGL((tamcmc_eval_kernel<KU, false>), grid, block, lds, stream, a);
 #ifdef TM_TRACE
-    if (tf && !grad) {
+    if (tf && grad == trace_grad) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(nblk * 4);
         (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         FILE *f = fopen(tf, "wb");
-        if (f) { long long dims[2] = {a.tiles, Nchains}; fwrite(dims, sizeof(dims), 1, f); fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+        if (f) { long long dims[2] = {(long long)grid.y, (long long)grid.x}; /* rows x columns of the launch grid */ fwrite(dims, sizeof(dims), 1, f); fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
     }
 #endif
     return (int)hipGetLastError();

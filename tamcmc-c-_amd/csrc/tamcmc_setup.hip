@@ -12,7 +12,7 @@
 #define TM_SETUP_THREADS 128   // wave 0: chain record + multiplets; wave 1 lane 0: noise record, concurrently
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
                                                           const double *__restrict__ Tcoefs, double *__restrict__ wt,
-                                                          const double *__restrict__ lx, int UB, int units, int tiles,
+                                                          const double *__restrict__ lx, int UB, int units, int big, int small, int tiles,
                                                           TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
                                                           TmTileRec *__restrict__ trec, int32_t *__restrict__ tidx,
                                                           TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         for (int tile = tid - 64; tile < tiles; tile += 64) {
-            const int base = TM_TILE_U0(tile, units, tiles) * UB, TB = TM_TILE_U0(tile + 1, units, tiles) * UB - base;
+            const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
             TmTileRec R;
             R.nact = 0;
             int ic = base + TB / 2; if (ic > L.Nx - 1) ic = L.Nx - 1;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
     // the multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel)
     const int nm = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
     for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) {
-        const int base = TM_TILE_U0(tile, units, tiles) * UB, TB = TM_TILE_U0(tile + 1, units, tiles) * UB - base;
+        const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
         int32_t *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
         int nact = 0, cost = 0;
         for (int j = 0; j < nm; j++)
@@ -212,11 +212,11 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
 }
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
-                    int units, int tiles, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
+                    int units, int big, int small, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
                     void *d_chain_rec, void *d_aux, double *d_hser, int32_t *d_order, void *stream)
 {
     hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
-                       d_params, d_Tcoefs, d_wt, d_lx, unit_bins, units, tiles, d_mult, d_noise, d_trec, d_tidx,
+                       d_params, d_Tcoefs, d_wt, d_lx, unit_bins, units, big, small, tm_tile_count(units, big, small), d_mult, d_noise, d_trec, d_tidx,
                        static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux), d_hser, d_order);
     return (int)hipGetLastError();
 }

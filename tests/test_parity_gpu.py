@@ -253,7 +253,7 @@ def test_large_grid_and_many_chains(accel_mod, orc):
 def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     """The eval launch is tile-major and costliest-first (rank table from the setup kernel).  Results must be bitwise
     the same for the chain-major order (TAMCMC_ORDER=0), plain tile-major (1) and ranked (2, default), and for a tile
-    count above TM_ORDER_MAX = 1024, where the rank table is the identity."""
+    count above TM_ORDER_MAX = 1024, where the rank table is the identity; and for tiles of two alternating sizes."""
     w = synth.workload_c2(Nx=30000)
     y = spectrum_for(orc, w)
     P = synth.chain_params(w, 5)
@@ -271,17 +271,31 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
     check_logL(res[2][0], rL)
     monkeypatch.delenv("TAMCMC_ORDER")
+    # two tile sizes: other partial sums, same answer to rounding; gradient against the uniform geometry
+    for env in (dict(TAMCMC_S="4", TAMCMC_S2="1", TAMCMC_S_GRAD="9", TAMCMC_S2_GRAD="2"),
+                dict(TAMCMC_S="2", TAMCMC_S2="2", TAMCMC_S_GRAD="5", TAMCMC_S2_GRAD="4")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+            acc.set_vars(w["index_to_relax"])
+            L, st = acc.eval_batch(P, T)
+            Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        check_logL(L, rL)
+        check_logL(Lg, rL)
+        assert np.max(np.abs(g - res[2][2]) / np.max(np.abs(res[2][2]), axis=1, keepdims=True)) < 1e-11
+        for k in env:
+            monkeypatch.delenv(k)
 
     w = synth.workload_c2(Nx=1200000)
     w["x"] = synth.grid(1200000, 2300.0, 840.0 / 1200000)
     y = spectrum_for(orc, w)
     P = synth.chain_params(w, 2)
     T = synth.temperatures(2)
-    monkeypatch.setenv("TAMCMC_TILES", "1100")
-    monkeypatch.setenv("TAMCMC_TILES_GRAD", "1100")
+    monkeypatch.setenv("TAMCMC_S", "1")          # 1024-bin likelihood tiles, 1024-bin gradient tiles: 1172 of each
+    monkeypatch.setenv("TAMCMC_S_GRAD", "2")
     with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
         acc.set_vars(w["index_to_relax"])
-        assert acc.geometry()["tiles"] == 1100
+        assert acc.geometry()["tiles"] == 1172
         L, st = acc.eval_batch(P, T)
         Lg, stg, g = acc.eval_batch(P, T, grad=True)
     rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)

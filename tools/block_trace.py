@@ -17,11 +17,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "tiny":
     q = 7 + 2 + 21 + 6 + 7 + 10
     P[:, q + 1] = 0.05
 acc = tamcmc_amd.Accel(2, w["plength"], w["x"], y)
+grad = os.environ.get("TAMCMC_TRACE_GRAD") is not None
+if grad:
+    acc.set_vars(w["index_to_relax"])
 for _ in range(5):
-    acc.eval_batch(P, T)
+    acc.eval_batch(P, T, grad=grad)
 raw = np.fromfile(tf, dtype=np.uint64)
-tiles, chains = int(raw[0]), int(raw[1])
-t = raw[2:].reshape(chains, tiles, 4)
+# launch grid: rows = blockIdx.y, columns = blockIdx.x.  Default (tile-major) order: row = rank of the tile in the
+# chain's costliest-first order, column = chain; TAMCMC_ORDER=0: row = chain, column = tile slot.
+rows, cols = int(raw[0]), int(raw[1])
+t = raw[2:].reshape(rows, cols, 4)
+if os.environ.get("TAMCMC_ORDER") != "0":
+    t = t.transpose(1, 0, 2)        # -> [chain][rank]
+chains, tiles = t.shape[0], t.shape[1]
 t0 = t[..., 0].min()
 start = (t[..., 0] - t0).astype(np.float64) * 0.01      # wall_clock64: 100 MHz -> us
 mid = (t[..., 1] - t0).astype(np.float64) * 0.01
@@ -42,4 +50,7 @@ order = np.argsort(start.ravel())
 flat_chain, flat_tile = np.unravel_index(order, start.shape)
 print("dispatch order (first 12 by start): ", [(int(c), int(tl)) for c, tl in zip(flat_chain[:12], flat_tile[:12])])
 per_tile = dur.mean(axis=0)
-print("mean duration per tile index:", np.round(per_tile, 1))
+print("mean duration per tile index / rank:", np.round(per_tile, 1))
+print("mean start per tile index / rank:", np.round(start.mean(axis=0), 1))
+print("mean end per tile index / rank:", np.round(end.mean(axis=0), 1))
+print("pass 1 share of a block (stamp0->1):", round(float(((mid - start) / dur).mean()), 3))

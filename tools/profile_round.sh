@@ -9,7 +9,8 @@ cd $R
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-sampler"
+# the bench at its defaults (200 timed steps after 500 warm-up steps: settled clocks), minus the CPU and sampler legs
+B="python3 $R/bench.py --no-cpu-baseline --no-sampler"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 && echo "stats ok"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1 && echo "pmc sq ok"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1 && echo "pmc fetch ok"
@@ -20,4 +21,4 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_clock -- python3 $
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/fetch_calib.hip -o $O/fetch_calib 2> /dev/null && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -- $O/fetch_calib > $O/calib_fetch.log 2>&1 && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib_write -- $O/fetch_calib > $O/calib_write.log 2>&1 && echo "calibration ok"; rm -f $O/fetch_calib
 cd $R && python tools/summarize_profiles.py $O
 # rehearsal of the N>1 bench path on this one GPU: 2 ranks over gloo, both on cuda:0
-cd $R && timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline --backend gloo --single-device > $O/bench_2rank_gloo_rehearsal.json 2> $O/bench_2rank.err; echo "2-rank rehearsal rc=$?"; cat $O/bench_2rank_gloo_rehearsal.json
+cd $R && timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --no-cpu-baseline --no-sampler --backend gloo --single-device > $O/bench_2rank_gloo_rehearsal.json 2> $O/bench_2rank.err; echo "2-rank rehearsal rc=$?"; cat $O/bench_2rank_gloo_rehearsal.json
