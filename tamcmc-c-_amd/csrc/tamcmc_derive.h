@@ -335,6 +335,8 @@ __device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const
 
     // ---- heights ----
     M.H = 0.0;
+#pragma unroll
+    for (int k = 0; k < TM_MAXM; k++) M.h[k] = 0.0;
     if (L.variant != 2) {
         // variants 0 and 1: H_l times the m-ratios
         M.idx_h = (L.family == TM_FAM_LOCAL) ? (off + n) : n;
@@ -344,7 +346,8 @@ __device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const
         } else {
             M.H = C.do_amp ? fabs(pn / (PI_L * M.W)) * C.Vl[l] : fabs(pn * C.Vl[l]);
         }
-        for (int k = 0; k < M.ncomp; k++) M.h[k] = M.H * C.ratios[l][k];
+#pragma unroll
+        for (int k = 0; k < TM_MAXM; k++) M.h[k] = (k < M.ncomp) ? M.H * C.ratios[l][k] : 0.0;
     } else {
         // variant 2: heights per |m| straight from params (ids 13, 14)
         if (l == 0) {
@@ -353,29 +356,36 @@ __device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const
         } else {
             M.idx_h = ((L.family == TM_FAM_LOCAL) ? off : L.q) + (l + 1) * n;
             const double den = PI_L * M.W;
-            for (int k = 0; k < M.ncomp; k++) {
-                int am = k - l; if (am < 0) am = -am;
-                double v = p[M.idx_h + am];
-                if (C.do_amp) v = v / den;
-                M.h[k] = fabs(v);
+#pragma unroll
+            for (int k = 0; k < TM_MAXM; k++) {
+                if (k < M.ncomp) {
+                    int am = k - l; if (am < 0) am = -am;
+                    double v = p[M.idx_h + am];
+                    if (C.do_amp) v = v / den;
+                    M.h[k] = fabs(v);
+                }
             }
         }
     }
 
     // ---- component frequencies ----  build_lorentzian.cpp:74-91 / :28-48
-    for (int k = 0; k < M.ncomp; k++) {
+    // (fixed trip count + predicate: the record stays in registers, the seven components are independent chains)
+#pragma unroll
+    for (int k = 0; k < TM_MAXM; k++) {
         const int m = k - l;
-        double Qlm = 0.0, clm = 0.0;
-        if (l != 0) {
-            Qlm = (double)(l * (l + 1) - 3 * m * m) / (double)((2 * l - 1) * (2 * l + 3));
-            if (l == 1) clm = (L.variant == 1) ? 0.0 : (double)m;
-            if (l == 2) clm = (5. * (double)(m * m * m) - 17. * m) / 3.;
-            if (l == 3) clm = 0.0;
-            M.nu[k] = M.f * (1. + C.eta * Qlm) + m * M.f_s + clm * C.a3;
-        } else {
-            M.nu[k] = M.f;
+        double Qlm = 0.0, clm = 0.0, nu = 0.0;
+        if (k < M.ncomp) {
+            if (l != 0) {
+                Qlm = (double)(l * (l + 1) - 3 * m * m) / (double)((2 * l - 1) * (2 * l + 3));
+                if (l == 1) clm = (L.variant == 1) ? 0.0 : (double)m;
+                if (l == 2) clm = (5. * (double)(m * m * m) - 17. * m) / 3.;
+                if (l == 3) clm = 0.0;
+                nu = M.f * (1. + C.eta * Qlm) + m * M.f_s + clm * C.a3;
+            } else {
+                nu = M.f;
+            }
         }
-        M.Q[k] = Qlm; M.c[k] = clm;
+        M.nu[k] = nu; M.Q[k] = Qlm; M.c[k] = clm;
     }
 
     // ---- truncation window ----

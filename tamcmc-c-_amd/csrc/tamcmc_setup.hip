@@ -28,7 +28,6 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
     // the caller's temperature array may live in host memory: read it once, now (latency hidden behind the work below)
     const double Tc = (tid == 64) ? Tcoefs[chain] : 1.0;
     __shared__ TmChain C;
-    __shared__ TmMultFull s_M[64];    // per-lane scratchpad: dynamically indexed fields stay out of scratch memory
     __shared__ int s_status;
     __syncthreads();
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 1
@@ -37,7 +36,9 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
 
     if (tid == 0) s_status = 0;
     if (L.family != TM_FAM_GAUSS) {
+#if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))   // timing-only build: no chain-level derivation
         tm_derive_chain_coop(L, p, C, tid);
+#endif
         // keep the chain record for the backward kernel (gradient path)
         if (chain_rec != nullptr)
             for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_SETUP_THREADS)
@@ -81,7 +82,11 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         // s_N was written by lane 0 of THIS wave: LDS operations of one wave complete in order.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 1)   // timing-only build: no tile polynomials
+        for (int tile = tiles; tile < tiles; tile += 64) {
+#else
         for (int tile = tid - 64; tile < tiles; tile += 64) {
+#endif
             const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
             TmTileRec R;
             R.nact = 0;
@@ -135,8 +140,12 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
     }
 
     if (L.family != TM_FAM_GAUSS && tid < 64) {
+#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 2)   // timing-only build: no multiplet derivation
+        for (int j = L.n_mult; j < L.n_mult; j += 64) {
+#else
         for (int j = tid; j < L.n_mult; j += 64) {
-            TmMultFull &M = s_M[tid];
+#endif
+            TmMultFull M;        // in registers: every array index inside is a compile-time constant
             tm_derive_mult(L, C, p, j, M);
             TmMult out;
             const double g2 = M.W * M.W;
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
                 const double cc = 0.5 * M.W * C.asym / M.f;
                 out.aA = C.asym / M.f; out.aB = 1.0 - C.asym; out.c2 = cc * cc; out.has_asym = 1;
             }
+#pragma unroll
             for (int k = 0; k < TM_MAXM; k++) {
                 if (k < M.ncomp) { out.nu2[k] = 2.0 * M.nu[k]; out.hq[k] = M.h[k] * g2; }
                 else             { out.nu2[k] = 0.0;           out.hq[k] = 0.0; }
