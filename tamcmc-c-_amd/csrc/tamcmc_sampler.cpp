@@ -4,6 +4,7 @@
 #include "tamcmc_sampler.h"
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -362,63 +363,78 @@ bool cholesky(const double *A, int n, double *L, double *W /* n*n + n scratch */
 
 // Fork-join helper for the per-chain host work (the reference runs its chain loop under OpenMP, MALA.cpp:632).
 // Every chain's arithmetic is sequential and independent of the others, so results do not depend on the thread count.
+// Fork-join over chains with a STATIC partition: participant p of P (the caller is participant 0) runs a contiguous
+// block of items.  No shared work counter: on a many-CCD host every contended fetch_add costs 100-300 ns,
+// and a dynamic queue spent ~20 us per fork on 64 items (measured); here a fork costs one epoch broadcast plus one
+// arrival per worker, each on its own cache line.  The fixed item -> thread map also keeps each chain's matrices in
+// the same core's cache.
 class ChainPool {
 public:
-    explicit ChainPool(int nthreads) { for (int t = 1; t < nthreads; t++) workers_.emplace_back([this] { loop(); }); }
+    explicit ChainPool(int nthreads) : P_(nthreads < 1 ? 1 : nthreads), slots_((size_t)(nthreads < 1 ? 1 : nthreads))
+    {
+        for (int t = 1; t < P_; t++) workers_.emplace_back([this, t] { loop(t); });
+    }
     ~ChainPool()
     {
-        { std::lock_guard<std::mutex> g(mx_); stop_ = true; epoch_.fetch_add(1, std::memory_order_release); }
+        { std::lock_guard<std::mutex> g(mx_); stop_ = true; hdr_.epoch.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         for (std::thread &t : workers_) t.join();
     }
-    int size() const { return (int)workers_.size() + 1; }
+    int size() const { return P_; }
     template <class F> void run(int n, F &&fn)
     {
         if (workers_.empty() || n < 2) { for (int i = 0; i < n; i++) fn(i); return; }
         std::function<void(int)> job = std::ref(fn);
-        job_.store(&job, std::memory_order_relaxed); n_.store(n, std::memory_order_relaxed);
-        done_.store(0, std::memory_order_relaxed); next_.store(0, std::memory_order_release);
-        { std::lock_guard<std::mutex> g(mx_); epoch_.fetch_add(1, std::memory_order_release); }
-        cv_.notify_all();
-        work();
-        while (done_.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
-        // a worker may still be between its last fetch of next_ and its return from work(): it touches only
-        // members, never `job`, after done_ reached n
+        hdr_.job.store(&job, std::memory_order_relaxed); hdr_.n.store(n, std::memory_order_relaxed);
+        uint64_t e;
+        { std::lock_guard<std::mutex> g(mx_); e = hdr_.epoch.fetch_add(1, std::memory_order_release) + 1; }
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+        for (int i = 0, hi = block_end(0, n); i < hi; i++) fn(i);
+        for (int p = 1; p < P_; p++)
+            while (slots_[(size_t)p].done.load(std::memory_order_acquire) != e) __builtin_ia32_pause();
     }
 
 private:
-    void work()
-    {
-        for (;;) {
-            const int i = next_.fetch_add(1, std::memory_order_acq_rel);
-            if (i >= n_.load(std::memory_order_relaxed)) return;
-            (*job_.load(std::memory_order_relaxed))(i);
-            done_.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void loop()
+    // what the caller writes and every worker polls / reads: one cache line, never written by a worker
+    struct alignas(64) Header {
+        std::atomic<uint64_t> epoch{0};
+        std::atomic<int> n{0};
+        std::atomic<const std::function<void(int)> *> job{nullptr};
+    };
+    // a worker's arrival flag (the epoch it has finished): its own cache line, so arrivals do not contend
+    struct alignas(64) Slot { std::atomic<uint64_t> done{0}; };
+    // participant p owns the contiguous items [block_end(p-1), block_end(p)): neighbours in the per-chain arrays
+    // belong to the same thread (no false sharing), and sizes differ by at most one item
+    int block_end(int p, int n) const { return (int)(((long long)(p + 1) * n) / P_); }
+    void loop(int p)
     {
         uint64_t seen = 0;
         for (;;) {
             // spin for a while (the next fork usually comes within one GPU evaluation), then sleep
-            uint64_t e = epoch_.load(std::memory_order_acquire);
-            for (int spin = 0; e == seen && spin < 40000; spin++) { __builtin_ia32_pause(); e = epoch_.load(std::memory_order_acquire); }
+            uint64_t e = hdr_.epoch.load(std::memory_order_acquire);
+            for (int spin = 0; e == seen && spin < 40000; spin++) { __builtin_ia32_pause(); e = hdr_.epoch.load(std::memory_order_acquire); }
             if (e == seen) {
                 std::unique_lock<std::mutex> g(mx_);
-                cv_.wait(g, [&] { return epoch_.load(std::memory_order_acquire) != seen; });
-                e = epoch_.load(std::memory_order_acquire);
+                sleepers_.fetch_add(1, std::memory_order_release);
+                cv_.wait(g, [&] { return hdr_.epoch.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_release);
+                e = hdr_.epoch.load(std::memory_order_acquire);
             }
             seen = e;
             if (stop_) return;
-            work();
+            const int n = hdr_.n.load(std::memory_order_relaxed);
+            const std::function<void(int)> &job = *hdr_.job.load(std::memory_order_relaxed);
+            for (int i = block_end(p - 1, n), hi = block_end(p, n); i < hi; i++) job(i);
+            slots_[(size_t)p].done.store(e, std::memory_order_release);
         }
     }
+    int P_ = 1;
+    Header hdr_;
+    std::vector<Slot> slots_;
     std::vector<std::thread> workers_;
     std::mutex mx_;
     std::condition_variable cv_;
-    std::atomic<uint64_t> epoch_{0};
-    std::atomic<int> next_{1 << 30}, done_{0}, n_{0};
-    std::atomic<const std::function<void(int)> *> job_{nullptr};
+    std::atomic<int> sleepers_{0};
     bool stop_ = false;
 };
 
@@ -451,7 +467,11 @@ struct tamcmc_sampler {
     std::vector<double> covar, sigma, mu, Lchol;
     std::vector<uint8_t> chol_valid;
     // scratch
-    std::vector<double> p_prop, v_prop, L_prop, u_mh, u_now, z, z_all, chol_scratch;
+    std::vector<double> p_prop, v_prop, L_prop, lpr_prop, u_mh, u_now, z, z_all, chol_scratch;
+    std::vector<int> perr_prop;
+    bool timing = false;             // developer switch TAMCMC_SAMPLER_TIMING=1: phase times of mh_step, printed at destroy
+    double t_phase[6] = {0, 0, 0, 0, 0, 0};   // proposals, launch, priors, draw-ahead, wait, accept (seconds)
+    int64_t t_iters = 0;
     std::vector<int32_t> status;
     std::vector<Rng::NormalPlan> plans;          // one per local chain (+1 for chains owned elsewhere)
     // The random numbers of an iteration do not depend on any outcome, so they are drawn one iteration ahead, while the
@@ -513,7 +533,7 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         }
         s->sigma[m] = std::pow(2.38, 2) * std::pow(s->T[cfg->chain_offset + m], 0.2) / nv;
     }
-    s->p_prop.resize((size_t)n * Nparams); s->v_prop.resize((size_t)n * nv); s->L_prop.resize(n);
+    s->p_prop.resize((size_t)n * Nparams); s->v_prop.resize((size_t)n * nv); s->L_prop.resize(n); s->lpr_prop.resize(n); s->perr_prop.resize(n);
     s->u_mh.resize(n); s->z.resize(nv); s->status.resize(n);
     s->plans.resize((size_t)n + 1);
     s->z_all.resize((size_t)n * nv); s->chol_scratch.resize((size_t)n * (2 * (size_t)nv * nv + nv));
@@ -524,6 +544,7 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         if (nt > n) nt = n;
         if (nt < 1) nt = 1;
         s->pool.reset(new ChainPool(nt));
+    { const char *e = getenv("TAMCMC_SAMPLER_TIMING"); s->timing = e && e[0] == '1'; }
     }
     s->rng.g.seed(cfg->seed);
     *out = s;
@@ -547,7 +568,16 @@ extern "C" int tamcmc_sampler_create_hip(tamcmc_sampler **out, const tamcmc_samp
     return rc;
 }
 
-extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s) { delete s; return TAMCMC_OK; }
+extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s)
+{
+    if (s && s->timing && s->t_iters > 0) {
+        const double k = 1e6 / (double)s->t_iters;
+        fprintf(stderr, "[tamcmc sampler] %lld iterations; us per iteration: proposals %.1f, launch %.1f, priors %.1f, draw-ahead %.1f, wait %.1f, accept %.1f\n",
+                (long long)s->t_iters, s->t_phase[0] * k, s->t_phase[1] * k, s->t_phase[2] * k, s->t_phase[3] * k, s->t_phase[4] * k, s->t_phase[5] * k);
+    }
+    delete s;
+    return TAMCMC_OK;
+}
 extern "C" int64_t tamcmc_sampler_iteration(const tamcmc_sampler *s) { return s ? s->iter : -1; }
 extern "C" int32_t tamcmc_sampler_nvars(const tamcmc_sampler *s) { return s ? s->Nvars : -1; }
 extern "C" int32_t tamcmc_sampler_nlocal(const tamcmc_sampler *s) { return s ? s->nloc : -1; }
@@ -649,6 +679,8 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     const double gamma = s->cfg.c0 / (1. + (double)i);             // MALA.cpp:630
     // 1. proposals.  Random draws first, in the reference's order: for each chain, u then z (MALA.cpp:451,465,346);
     //    then the per-chain linear algebra, chains in parallel.
+    auto now = [&]() { return s->timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0; };
+    double t0 = now(), t1;
     if (!s->drawn_ahead) {
         draw_mh(s);
         s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
@@ -676,6 +708,7 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
     });
     s->bad_chol += bad.load();
+    t1 = now(); s->t_phase[0] += t1 - t0; t0 = t1;
     // 2. the hot path: every local chain in one call.  While the GPU works, consume the stream one iteration ahead:
     //    the parallel-tempering draws of THIS iteration (MALA.cpp:384,390; they come first in the stream), then the
     //    MH draws of the next one and their Box-Muller transforms.  u_mh of this iteration is kept aside first.
@@ -683,14 +716,29 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     if (s->hip_ctx) {
         rc = tamcmc_eval_batch_begin(s->hip_ctx, n, np, s->p_prop.data(), &s->T[off]);
         if (rc != TAMCMC_OK) return rc;
+        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
         s->u_now = s->u_mh;
+        // the priors of the proposals need nothing from the GPU: off the critical path
+        s->pool->run(n, [&](int m) {
+            int perr = 0;
+            s->lpr_prop[m] = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+            s->perr_prop[m] = perr;
+        });
+        t1 = now(); s->t_phase[2] += t1 - t0; t0 = t1;
         if (tamcmc_sampler_pt_due(s) && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
         draw_mh(s);
         s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
         s->drawn_ahead = true;
+        t1 = now(); s->t_phase[3] += t1 - t0; t0 = t1;
         rc = tamcmc_eval_batch_end(s->hip_ctx, n, s->L_prop.data(), s->status.data());
+        t1 = now(); s->t_phase[4] += t1 - t0; t0 = t1;
     } else {
         s->u_now = s->u_mh;
+        s->pool->run(n, [&](int m) {
+            int perr = 0;
+            s->lpr_prop[m] = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+            s->perr_prop[m] = perr;
+        });
         rc = s->eval(s->eval_user, n, np, s->p_prop.data(), &s->T[off], s->L_prop.data(), s->status.data());
     }
     if (rc != TAMCMC_OK) return rc;
@@ -698,10 +746,9 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     int64_t period = 1;
     const bool learn = learning_now(s, i, &period);
     std::atomic<int> perr_any{0};
-    s->pool->run(n, [&](int m) {
-        int perr = 0;
-        const double lpr = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
-        if (perr) perr_any.store(1, std::memory_order_relaxed);
+    auto accept = [&](int m) {
+        const double lpr = s->lpr_prop[m];
+        if (s->perr_prop[m]) perr_any.store(1, std::memory_order_relaxed);
         const double lpo = s->L_prop[m] + lpr;
         double r;
         if (!std::isnan(s->L_prop[m])) {
@@ -720,7 +767,11 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         }
         s->Pmove[m] = r;
         if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
-    });
+    };
+    // (the fixed chain -> thread map of the pool keeps a chain's rows in the cache of the core that proposed them:
+    // even the short accept step without adaptation is cheaper forked than pulled over to the calling thread)
+    s->pool->run(n, accept);
+    t1 = now(); s->t_phase[5] += t1 - t0; s->t_iters++;
     const int perr = perr_any.load();
     return perr ? TAMCMC_E_INVALID : TAMCMC_OK;
 }
