@@ -365,6 +365,13 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
         chain = blockIdx.x;
         tile = (a.order_mode == 2) ? a.order[(size_t)chain * a.tiles + blockIdx.y] : (int)blockIdx.y;
     }
+    // Issue priority by launch rank: the costliest quarter of a chain's tiles runs at priority 3, the next at 2, 1, 0.
+    // Waves are served oldest-first anyway; this keeps a late-placed cheap workgroup from slowing the long ones it
+    // joins (measured: the opposite assignment costs 4 %, this one gains ~1 %; profiles/README.md).
+    if (a.order_mode != 0) {
+        const int r4 = (4 * (int)blockIdx.y) / a.tiles;
+        if (r4 == 0) __builtin_amdgcn_s_setprio(3); else if (r4 == 1) __builtin_amdgcn_s_setprio(2); else if (r4 == 2) __builtin_amdgcn_s_setprio(1);
+    }
     TmNoiseK sn = (TmNoiseK)(a.noise + chain);
     const int u_first = TM_TILE_U0(tile, a.tile_big, a.tile_small);
     const int S = TM_TILE_S(tile, a.tile_big, a.tile_small, a.units);   // sub-blocks of this tile
