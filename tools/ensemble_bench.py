@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Developer tool: BASELINE config C5 on one GPU -- several independent stars, 16 chains each, one context (own HIP
+stream) per star, all driven from ONE host thread with device-resident inputs (launches are asynchronous, so the
+streams overlap on the GPU).  Prints the aggregate rate against one context holding the same number of chains.
+
+    python tools/ensemble_bench.py [stars=4] [chains_per_star=16] [steps=300]
+"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tamcmc_amd
+from tamcmc_amd import synth
+
+nstars = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+nch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+dev = torch.device("cuda", 0)
+
+
+def make(n_chains, seed):
+    w = synth.workload_c2()
+    y = np.abs(np.sin(np.arange(w["x"].size) + seed)) + 0.5
+    acc = tamcmc_amd.Accel(2, w["plength"], w["x"], y)
+    acc.set_vars(w["index_to_relax"])
+    P = torch.from_numpy(synth.chain_params(w, n_chains, seed=seed)).to(dev)
+    T = torch.from_numpy(synth.temperatures(n_chains)).to(dev)
+    L = torch.empty(n_chains, dtype=torch.float64, device=dev)
+    G = torch.empty(n_chains, w["index_to_relax"].size, dtype=torch.float64, device=dev)
+    S = torch.empty(n_chains, dtype=torch.int32, device=dev)
+    return acc, (n_chains, P, T, L, G, S)
+
+
+def step(acc, b, grad):
+    n, P, T, L, G, S = b
+    acc.eval_batch_device(n, P.data_ptr(), T.data_ptr(), L.data_ptr(), G.data_ptr() if grad else 0, S.data_ptr())
+
+
+def rate(ctxs, grad):
+    for _ in range(300):
+        for acc, b in ctxs:
+            step(acc, b, grad)
+    for acc, _ in ctxs:
+        acc.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for acc, b in ctxs:
+            step(acc, b, grad)
+    for acc, _ in ctxs:
+        acc.synchronize()
+    dt = time.perf_counter() - t0
+    return sum(b[0] for _, b in ctxs) * steps / dt
+
+
+def rate_threads(ctxs, grad):
+    """one host thread per star (the GIL is released inside the C call)"""
+    import threading
+    def loop(acc, b, n):
+        for _ in range(n):
+            step(acc, b, grad)
+        acc.synchronize()
+    th = [threading.Thread(target=loop, args=(a, b, 300)) for a, b in ctxs]
+    [t.start() for t in th]; [t.join() for t in th]
+    th = [threading.Thread(target=loop, args=(a, b, steps)) for a, b in ctxs]
+    t0 = time.perf_counter()
+    [t.start() for t in th]; [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    return sum(b[0] for _, b in ctxs) * steps / dt
+
+
+ens = [make(nch, 11 + k) for k in range(nstars)]
+one = [make(nch * nstars, 5)]
+single = [ens[0]]
+for grad in (True, False):
+    r_e, r_1, r_s = rate(ens, grad), rate(one, grad), rate(single, grad)
+    r_t = rate_threads(ens, grad)
+    print(f"{'logL+grad' if grad else 'logL only'}: {nstars} stars x {nch} chains on {nstars} streams {r_e:,.0f} chain-steps/s "
+          f"(one host thread per star: {r_t:,.0f}); "
+          f"one context x {nch * nstars} chains {r_1:,.0f}; one star x {nch} chains alone {r_s:,.0f}")
