@@ -37,7 +37,6 @@ struct tamcmc_ctx {
     int Kg = 2, Sg = 8, Sg2 = 8;   // with gradient partials: 2 bins in flight; tiles of Sg / Sg2 sub-blocks of 512 bins (32 KB of LDS)
     int units = 0, units_g = 0;    // sub-blocks in the grid at K / Kg
     int tiles_cap = 0, tiles_g_cap = 0;   // tiles of the two geometries (buffers are sized for them)
-    int slots = 0, slots_g = 0;    // resident workgroups of the two kernels on this device
     int last_tiles = 0;            // T of the most recent likelihood-only call (tamcmc_ctx_geometry)
     int tiles_max = 0;
     hipStream_t own_stream = nullptr;
@@ -268,15 +267,6 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     if (hipSetDevice(device_id) != hipSuccess) return fail(TAMCMC_E_NODEVICE);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(TAMCMC_E_HIP);
     c->stream = c->own_stream;
-    {   // resident workgroups: the likelihood kernel fits 7 per CU (registers), the gradient kernel 4 (LDS, registers)
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < 1) cus = 256;
-        c->slots = cus * 7;
-        c->slots_g = cus * 4;
-        int v = 0;
-        const char *e = getenv("TAMCMC_SLOTS");      if (e && (v = atoi(e)) > 0) c->slots = v;
-        e = getenv("TAMCMC_SLOTS_GRAD");             if (e && (v = atoi(e)) > 0) c->slots_g = v;
-    }
     const size_t bytes = (size_t)Nx * sizeof(double);
     if (hipMalloc(&c->d_x, bytes) != hipSuccess || hipMalloc(&c->d_y, bytes) != hipSuccess ||
         hipMalloc(&c->d_lx, bytes) != hipSuccess)
