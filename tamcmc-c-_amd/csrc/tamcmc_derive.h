@@ -272,8 +272,10 @@ __device__ __forceinline__ void tm_mult_nl(const TmLayout &L, int j, int *n, int
     }
 }
 
-// Everything about multiplet j of the chain whose params row is p.
-__device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const double *p, int j, TmMultFull &M)
+// Everything about multiplet j of the chain whose params row is p, EXCEPT the heights of variants 0 and 1, which
+// need the m-ratios (C.ratios): tm_mult_apply_ratios completes the record.  Needs C's scalars only, so a workgroup
+// can derive the ratios on another wave meanwhile.
+__device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, const double *p, int j, TmMultFull &M)
 {
     const double PI_L = 3.141592653589793238462643383279502884; // long double in the reference; fp64 on the device
     const int id = L.model_case;
@@ -346,8 +348,7 @@ __device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const
         } else {
             M.H = C.do_amp ? fabs(pn / (PI_L * M.W)) * C.Vl[l] : fabs(pn * C.Vl[l]);
         }
-#pragma unroll
-        for (int k = 0; k < TM_MAXM; k++) M.h[k] = (k < M.ncomp) ? M.H * C.ratios[l][k] : 0.0;
+        // (the products with the m-ratios are applied by tm_mult_apply_ratios, once the ratios exist)
     } else {
         // variant 2: heights per |m| straight from params (ids 13, 14)
         if (l == 0) {
@@ -390,4 +391,19 @@ __device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const
 
     // ---- truncation window ----
     M.status = tm_window(L, M.f, M.f_s_win, M.W, l, C.trunc_c, &M.imin, &M.imax);
+}
+
+// h_m = H_l times the m-ratio (variants 0 and 1; variant 2 read its heights from params already)
+__device__ __forceinline__ void tm_mult_apply_ratios(const TmLayout &L, const TmChain &C, TmMultFull &M)
+{
+    if (L.variant != 2) {
+#pragma unroll
+        for (int k = 0; k < TM_MAXM; k++) M.h[k] = (k < M.ncomp) ? M.H * C.ratios[M.l][k] : 0.0;
+    }
+}
+
+__device__ inline void tm_derive_mult(const TmLayout &L, const TmChain &C, const double *p, int j, TmMultFull &M)
+{
+    tm_derive_mult_pre(L, C, p, j, M);
+    tm_mult_apply_ratios(L, C, M);
 }

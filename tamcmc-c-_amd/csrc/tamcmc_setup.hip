@@ -9,7 +9,7 @@
 #include "tamcmc_dev.h"
 #include "tamcmc_derive.h"
 
-#define TM_SETUP_THREADS 128   // wave 0: chain record + multiplets; wave 1 lane 0: noise record, concurrently
+#define TM_SETUP_THREADS 192   // wave 0: multiplets; wave 1: noise record + tile polynomials; wave 2: m-ratios -- concurrently
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
                                                           const double *__restrict__ Tcoefs, double *__restrict__ wt,
                                                           const double *__restrict__ lx, int UB, int units, int big, int small, int tiles,
@@ -35,16 +35,19 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
 #endif
 
     if (tid == 0) s_status = 0;
-    if (L.family != TM_FAM_GAUSS) {
+    // phase 1: the chain's scalars (one lane); everything below needs them
+    if (L.family != TM_FAM_GAUSS && tid == 0) {
 #if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))   // timing-only build: no chain-level derivation
-        tm_derive_chain_coop(L, p, C, tid);
+        tm_derive_chain_scalars(L, p, C);
 #endif
-        // keep the chain record for the backward kernel (gradient path)
-        if (chain_rec != nullptr)
-            for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_SETUP_THREADS)
-                reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
-    } else {
-        __syncthreads();
+    }
+    __syncthreads();
+    // phase 2, three waves side by side: wave 2 the m-ratios from the inclination, wave 1 the noise record and the
+    // tile polynomials, wave 0 every multiplet's record up to the products with those ratios
+    if (L.family != TM_FAM_GAUSS && tid >= 128) {
+#if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))
+        tm_derive_chain_ratios(L, C, tid - 128);
+#endif
     }
 
     __shared__ TmNoise s_N;           // N.H[N.nh] is dynamically indexed: LDS, not scratch
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         const double n0 = p[z + Nnoise - 1];
         N.N0 = (take_abs ? fabs(n0) : n0) + extra;
     }
-    if (tid >= 64) {
+    if (tid >= 64 && tid < 128) {
         // Wave 1, concurrently with wave 0's multiplet derivation: the Harvey background of every tile as Taylor
         // polynomials in z = p (log x - log x_c).  u(z) = 1/(1 + t0 e^z) is analytic for |z| < pi (nearest pole at
         // ln(1/t0) + i pi), so for |z| <= 0.04 the series truncated at degree 8 is exact to (0.04/pi)^9 ~ 1e-17.
@@ -139,14 +142,24 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
         }
     }
 
-    if (L.family != TM_FAM_GAUSS && tid < 64) {
+    // wave 0: lane j derives multiplet j up to the ratio products, waits for the ratios, finishes it; chains with more
+    // than 64 multiplets do the rest afterwards in one go
+    TmMultFull M;        // in registers: every array index inside is a compile-time constant
 #if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 2)   // timing-only build: no multiplet derivation
-        for (int j = L.n_mult; j < L.n_mult; j += 64) {
+    const int n_mult = 0;
 #else
-        for (int j = tid; j < L.n_mult; j += 64) {
+    const int n_mult = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
 #endif
-            TmMultFull M;        // in registers: every array index inside is a compile-time constant
-            tm_derive_mult(L, C, p, j, M);
+    const bool first = tid < 64 && tid < n_mult;
+    if (first) tm_derive_mult_pre(L, C, p, tid, M);
+    __syncthreads();     // ratios (wave 2) and the chain record are complete
+    if (L.family != TM_FAM_GAUSS && chain_rec != nullptr)   // keep the chain record for the backward kernel (gradient path)
+        for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_SETUP_THREADS)
+            reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
+    if (tid < 64) {
+        for (int j = tid; j < n_mult; j += 64) {
+            if (j == tid) { if (first) tm_mult_apply_ratios(L, C, M); }
+            else tm_derive_mult(L, C, p, j, M);
             TmMult out;
             const double g2 = M.W * M.W;
             out.g2 = g2;
