@@ -256,6 +256,11 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
         const int64_t UB = (int64_t)TM_THREADS * c->K, UBg = (int64_t)TM_THREADS * c->Kg;
         c->units = (int)((Nx + UB - 1) / UB);
         c->units_g = (int)((Nx + UBg - 1) / UBg);
+        // Short grids get smaller tiles, so that a chain still spreads over ~10 workgroups (a workgroup's run time is
+        // the floor of the launch: at 1e4 bins the defaults above would take 59 us per gradient step, these take 36-40).
+        // A function of the grid alone, like everything else about the geometry.
+        if (!getenv("TAMCMC_S")) { const int s = c->units / 10; if (s < c->S) c->S = s < 1 ? 1 : s; }
+        if (!getenv("TAMCMC_S_GRAD")) { const int s = c->units_g / 10; if (s < c->Sg) { c->Sg = s < 1 ? 1 : s; c->Sg2 = c->Sg; } }
         if (c->S2 > c->S) c->S2 = c->S;
         if (c->Sg2 > c->Sg) c->Sg2 = c->Sg;
         c->tiles_cap = tm_tile_count(c->units, c->S, c->S2);

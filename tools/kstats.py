@@ -10,23 +10,26 @@ import torch
 import tamcmc_amd
 from tamcmc_amd import synth
 
-w = synth.workload_c2()
-n = 64
+# usage: kstats.py [c2|c4|c1] [chains]
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+w = {"c2": synth.workload_c2, "c4": synth.workload_c4, "c1": synth.workload_c1}[which]()
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 P = synth.chain_params(w, n); T = synth.temperatures(n)
 y = np.abs(np.sin(np.arange(w["x"].size))) + 0.5
-acc = tamcmc_amd.Accel(2, w["plength"], w["x"], y)
+acc = tamcmc_amd.Accel(w["model_case"], w["plength"], w["x"], y)
 acc.set_vars(w["index_to_relax"])
 dev = torch.device("cuda", 0)
 acc.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 dP = torch.from_numpy(P).to(dev); dT = torch.from_numpy(T).to(dev)
-dL = torch.empty(n, dtype=torch.float64, device=dev); dG = torch.empty(n, 44, dtype=torch.float64, device=dev)
+dL = torch.empty(n, dtype=torch.float64, device=dev); dG = torch.empty(n, w["index_to_relax"].size, dtype=torch.float64, device=dev)
 dS = torch.empty(n, dtype=torch.int32, device=dev)
 for grad in (True, False):
-    for _ in range(20):
+    for _ in range(400):
         acc.eval_batch_device(n, dP.data_ptr(), dT.data_ptr(), dL.data_ptr(), dG.data_ptr() if grad else 0, dS.data_ptr())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(200):
         acc.eval_batch_device(n, dP.data_ptr(), dT.data_ptr(), dL.data_ptr(), dG.data_ptr() if grad else 0, dS.data_ptr())
     torch.cuda.synchronize()
-    print(f"grad={int(grad)} step {(time.perf_counter() - t0) / 200 * 1e6:.1f} us")
+    dt = (time.perf_counter() - t0) / 200
+    print(f"{which} {n} chains x {w['x'].size} bins, {w['plength'].sum()} params, {w['index_to_relax'].size} variables: grad={int(grad)} step {dt * 1e6:.1f} us = {n / dt:,.0f} chain-steps/s")
