@@ -143,9 +143,9 @@ def workload_c2(model_case=2, Nx=100000, asym=0.0, trunc_c=20.0, do_amp=False):
     return _global_workload(model_case, modes, [1.5, 0.53], 1.4, 55.0, 1e-5, 0.01, asym, _KPLR_NOISE, trunc_c, do_amp, x)
 
 
-def workload_c4(model_case=2, Nx=100000, asym=0.0, trunc_c=20.0):
+def workload_c4(model_case=2, Nx=100000, asym=0.0, trunc_c=20.0, Nmax=14):
     """C4: Nmax=14, l=0..3 -> 106 params; nu = Dnu (n + l/2 + eps) - l(l+1) D0."""
-    Dnu, eps, D0, n0, Nmax = 60.0, 1.4, 0.9, 38, 14
+    Dnu, eps, D0, n0 = 60.0, 1.4, 0.9, 38
     numax = Dnu * (n0 + Nmax / 2.0 + eps)
     modes = []
     for l in range(4):

@@ -303,3 +303,32 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     check_logL(L, rL)
     check_logL(Lg, rL)
     assert np.all(np.isfinite(g))
+
+
+def test_more_than_64_multiplets(accel_mod, orc):
+    """Nmax = 20, l = 0..3: 80 multiplets per chain -- the setup kernel's second pass over its multiplet lanes, the
+    eval kernel's long active lists, and 136 gradient variables."""
+    w = synth.workload_c4(Nx=30000, Nmax=20)
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 3)
+    T = synth.temperatures(3)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        assert acc.geometry()["n_multiplets"] == 80
+        acc.set_vars(w["index_to_relax"])
+        L, st = acc.eval_batch(P, T)
+        Lg, stg, g = acc.eval_batch(P, T, grad=True)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst) and np.array_equal(stg, rst)
+    check_logL(L, rL)
+    check_logL(Lg, rL)
+    # a few gradient entries against central differences of the oracle (all variables would take minutes)
+    idx = w["index_to_relax"]
+    pick = idx[[0, 21, 45, 80, idx.size - 12, idx.size - 1]]
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(pick)
+        _, _, gp = acc.eval_batch(P[:1], T[:1], grad=True)
+    gfd, st2 = orc.grad_fd(2, w["plength"], w["x"], y, P[0], T[0], pick, rel_step=1e-6)
+    assert st2 == 0
+    assert np.max(np.abs(gp[0] - gfd)) <= 2e-4 * np.max(np.abs(gfd))       # windows are on (trunc_c = 20): FD sees their edges
+    cols = [int(np.flatnonzero(idx == v)[0]) for v in pick]
+    assert np.array_equal(gp[0], g[0][cols])
