@@ -202,22 +202,30 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const int l = M.l;
         const double W = M.W, g2 = W * W, f = M.f;
         double adj_g2 = 0.0, adj_f = 0.0, adj_W = 0.0, adj_fs = 0.0;
-        for (int k = 0; k < M.ncomp; k++) {
-            const double hq = M.h[k] * g2;
-            const double adj_hq = G[3 * k];
-            const double adj_nu = 4.0 * hq * G[3 * k + 1];
-            adj_g2 += -hq * G[3 * k + 2] + adj_hq * M.h[k];
-            adj_h[k] = adj_hq * g2;
-            const int m = k - l;
-            if (l != 0) {
-                adj_f += adj_nu * (1. + C.eta * M.Q[k]);
-                sh[SL_ETA] += adj_nu * f * M.Q[k];
-                adj_fs += adj_nu * (double)m;
-                sh[SL_A3] += adj_nu * M.c[k];
-            } else {
-                adj_f += adj_nu;
+        // (fixed trip count + predicate: the loads of the seven components are issued together; the two chain-level
+        // sums are kept in registers instead of read-modify-write cycles on LDS -- same order of additions)
+        double s_eta = 0.0, s_a3 = 0.0;
+        const int ncomp = M.ncomp;
+#pragma unroll
+        for (int k = 0; k < TM_MAXM; k++) {
+            if (k < ncomp) {
+                const double hq = M.h[k] * g2;
+                const double adj_hq = G[3 * k];
+                const double adj_nu = 4.0 * hq * G[3 * k + 1];
+                adj_g2 += -hq * G[3 * k + 2] + adj_hq * M.h[k];
+                adj_h[k] = adj_hq * g2;
+                const int m = k - l;
+                if (l != 0) {
+                    adj_f += adj_nu * (1. + C.eta * M.Q[k]);
+                    s_eta += adj_nu * f * M.Q[k];
+                    adj_fs += adj_nu * (double)m;
+                    s_a3 += adj_nu * M.c[k];
+                } else {
+                    adj_f += adj_nu;
+                }
             }
         }
+        if (l != 0) { sh[SL_ETA] = s_eta; sh[SL_A3] = s_a3; }      // the slots were zero
         adj_W += 2.0 * W * adj_g2;
         if (C.asym != 0) {
             const double al = C.asym;
@@ -246,9 +254,14 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const double piW = PI * W;
         if (L.variant != 2) {
             double adj_H = 0.0;
-            for (int k = 0; k < M.ncomp; k++) {
-                adj_H += adj_h[k] * C.ratios[l][k];
-                if (l > 0) { int am = k - l; if (am < 0) am = -am; sh[tm_ratio_slot(l, am)] += adj_h[k] * M.H; }
+#pragma unroll
+            for (int k = 0; k < TM_MAXM; k++)
+                if (k < ncomp) adj_H += adj_h[k] * C.ratios[l][k];
+            // ratio slot |m| collects component l-|m|, then l+|m| (the order of the component loop); the slots were zero
+            for (int am = 0; am <= l && l > 0; am++) {
+                double r = adj_h[l - am] * M.H;
+                if (am > 0) r += adj_h[l + am] * M.H;
+                sh[tm_ratio_slot(l, am)] = r;
             }
             const double pn = p[M.idx_h];
             const bool plain = (l == 0 || L.family == TM_FAM_LOCAL);
