@@ -189,8 +189,8 @@ def main():
         cfg = S.default_cfg(nchains, seed=7, Nt_learn=(20, 60, 10 ** 9), periods_learn=(1, 1), prior_fct_switch=0, dN_mixing=1)
         smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], w["err"])
         smp.init()
-        smp.run(60, history=False)
-        n_s = max(50, min(2 * args.steps, 400))
+        smp.run(200, history=False)
+        n_s = max(50, min(10 * args.steps, 2000))      # ~0.25 s per leg: shorter legs scatter by 20 %
         t0 = time.perf_counter()
         moved, _ = smp.run(n_s)
         el = time.perf_counter() - t0
@@ -204,7 +204,7 @@ def main():
         cfg = S.default_cfg(nchains, seed=7, Nt_learn=(10 ** 9, 10 ** 9 + 1, 10 ** 9 + 2), periods_learn=(1, 1), prior_fct_switch=0, dN_mixing=1)
         smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], 0.05 * w["err"])
         smp.init()
-        smp.run(20, history=False)
+        smp.run(200, history=False)
         t0 = time.perf_counter()
         smp.run(n_s, history=False)
         el = time.perf_counter() - t0
