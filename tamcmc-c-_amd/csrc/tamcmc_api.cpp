@@ -49,6 +49,7 @@ struct tamcmc_ctx {
     double *d_params = nullptr, *d_T = nullptr, *d_logL = nullptr, *d_part = nullptr;
     double *d_gmult = nullptr, *d_gnoise = nullptr, *d_grad = nullptr, *d_hser = nullptr;
     int32_t *d_order = nullptr; int order_mode = 2;
+    int fuse = 1;                  // one tile per chain -> prologue and evaluation in one launch (TAMCMC_FUSED=0 disables)
     int32_t *d_status = nullptr, *d_rows = nullptr;
     TmMult *d_mult = nullptr;
     TmNoise *d_noise = nullptr;
@@ -250,6 +251,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_S2_GRAD", 1, 16, &c->Sg2);
     { int v = 0; env_int("TAMCMC_BG_EXACT", 0, 1, &v); c->L.bg_exact = v; }
     env_int("TAMCMC_ORDER", 0, 2, &c->order_mode);
+    env_int("TAMCMC_FUSED", 0, 1, &c->fuse);
     if (c->K == 3) c->K = 4;
     if (c->Kg == 3) c->Kg = 2;
     {
@@ -259,8 +261,10 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
         // Short grids get smaller tiles, so that a chain still spreads over ~10 workgroups (a workgroup's run time is
         // the floor of the launch: at 1e4 bins the defaults above would take 59 us per gradient step, these take 36-40).
         // A function of the grid alone, like everything else about the geometry.
-        if (!getenv("TAMCMC_S")) { const int s = c->units / 10; if (s < c->S) c->S = s < 1 ? 1 : s; }
-        if (!getenv("TAMCMC_S_GRAD")) { const int s = c->units_g / 10; if (s < c->Sg) { c->Sg = s < 1 ? 1 : s; c->Sg2 = c->Sg; } }
+        // And the shortest grids (<= 2048 bins, e.g. the ~1000-bin slices of a local fit) are one tile: then the
+        // prologue and the evaluation share a launch (tamcmc_fused.hip), which is what counts when a step is ~2 us of work.
+        if (!getenv("TAMCMC_S")) { const int s = c->units <= 2 ? c->units : c->units / 10; if (s < c->S) c->S = s < 1 ? 1 : s; }
+        if (!getenv("TAMCMC_S_GRAD")) { const int s = c->units_g <= 4 ? c->units_g : c->units_g / 10; if (s < c->Sg) { c->Sg = s < 1 ? 1 : s; c->Sg2 = c->Sg; } }
         if (c->S2 > c->S) c->S2 = c->S;
         if (c->Sg2 > c->Sg) c->Sg2 = c->Sg;
         c->tiles_cap = tm_tile_count(c->units, c->S, c->S2);
@@ -397,9 +401,6 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int tiles = pick_tiles(c, Nchains, grad);
     const int big = grad ? c->Sg : c->S, small = grad ? c->Sg2 : c->S2;
     if (!grad) c->last_tiles = tiles;
-    int rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, big, small, c->d_mult, c->d_noise, c->d_trec,
-                             c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr, c->order_mode == 2 ? c->d_order : nullptr, c->stream);
-    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
     a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.wt = c->d_wt;
@@ -409,8 +410,18 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
     a.units = units; a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0;
+    if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
     a.tile_big = big; a.tile_small = small;
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
+    // one tile per chain (short grids): prologue and evaluation share a launch
+    const bool fused = (tiles == 1) && c->fuse != 0;
+    int rc = 0;
+    if (!fused) {
+        rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, big, small, c->d_mult, c->d_noise,
+                             c->d_trec, c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr,
+                             c->order_mode == 2 ? c->d_order : nullptr, c->stream);
+        if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    }
     if (c->profile) {
         while (c->ev.size() < c->ev_used + 2) {
             hipEvent_t e;
@@ -419,7 +430,15 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
         }
         TM_HIP(hipEventRecord(c->ev[c->ev_used], c->stream));
     }
-    rc = tm_launch_eval(a, Nchains, K, grad, c->stream);
+    if (fused) {
+        TmFusedArgs f{};
+        f.params = d_params; f.Tcoefs = d_T;
+        f.chain_rec = grad ? c->d_chain_rec : nullptr; f.aux = grad ? c->d_aux : nullptr; f.hser = grad ? c->d_hser : nullptr;
+        f.p_doubles = (c->L.Nparams + 1) & ~1;
+        rc = tm_launch_fused(c->L, f, a, Nchains, K, grad, c->stream);
+    } else {
+        rc = tm_launch_eval(a, Nchains, K, grad, c->stream);
+    }
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "eval launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     if (c->profile) {
         TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], c->stream));

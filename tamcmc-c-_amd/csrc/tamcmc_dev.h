@@ -123,6 +123,15 @@ static inline int tm_tile_count(int units, int big, int small)
     return 2 * n + (rem > 0 ? 1 : 0) + (rem > big ? 1 : 0);
 }
 
+// What the fused small-grid launch (tamcmc_fused.hip) needs on top of TmEvalArgs: the inputs and the gradient-path
+// outputs of the prologue.
+struct TmFusedArgs {
+    const double *params, *Tcoefs;
+    void *chain_rec, *aux;      // NULL on the likelihood-only path
+    double *hser;               // NULL on the likelihood-only path
+    int32_t p_doubles, pad;     // LDS doubles reserved for the params row (Nparams rounded up to even)
+};
+
 #ifdef __cplusplus
 extern "C++" {
 // launchers implemented in the .hip files
@@ -135,6 +144,8 @@ int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, cons
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
+// setup + eval in one launch; requires a.tiles == 1
+int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
 int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units, int big, int small, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,

@@ -1,0 +1,60 @@
+// tamcmc_fused.hip -- short grids (one tile per chain): the per-chain prologue and the evaluation in ONE launch.
+//
+// A local fit of the reference's own example has ~1000 bins and ten chains: there the step is launch latency, not
+// arithmetic (setup 9.5 us + eval 6 us + the gap, against ~2 us of work).  When the geometry gives every chain a single
+// tile, workgroup c runs tm_setup_body for chain c (tamcmc_setup_body.h: same code, same non-contracted arithmetic as
+// tamcmc_setup_kernel) and then tm_eval_body for the chain's only tile (tamcmc_eval_body.h: same code as
+// tamcmc_eval_kernel), so the results are those of the two-launch path bit for bit.
+//
+// The eval body reads the records through the constant address space (scalar loads).  Here the same launch has just
+// written them, so (i) the stores are made visible first (__threadfence: vector stores reach L2, which the scalar cache
+// misses into; nothing can be stale in the scalar cache, these addresses have not been read in this launch), and (ii)
+// the pointers handed to the eval body are passed through an opaque asm, so that the compiler cannot schedule a
+// constant-address-space load -- which it may otherwise move anywhere -- ahead of the barrier.
+#include <hip/hip_runtime.h>
+#include "tamcmc_dev.h"
+#include "tamcmc_setup_body.h"
+#include "tamcmc_eval_body.h"
+
+template <int KU, bool GRAD>
+__global__ __launch_bounds__(TM_THREADS) void tamcmc_fused_kernel(TmLayout L, TmFusedArgs f, TmEvalArgs a)
+{
+    extern __shared__ double s_dyn[];   // [f.p_doubles] this chain's params row, then [TM_THREADS * KU * S] weights (GRAD)
+    const int chain = blockIdx.x;
+    tm_setup_body<TM_THREADS>(L, chain, f.params, f.Tcoefs, const_cast<double *>(a.wt), a.lx, TM_THREADS * KU, a.units, a.tile_big,
+                              a.tile_small, 1, const_cast<TmMult *>(a.mult), const_cast<TmNoise *>(a.noise),
+                              const_cast<TmTileRec *>(a.trec), const_cast<int32_t *>(a.tidx), static_cast<TmChain *>(f.chain_rec),
+                              static_cast<TmMultFull *>(f.aux), f.hser, nullptr, s_dyn);
+    __threadfence();
+    __syncthreads();
+    TmEvalArgs b = a;
+    asm volatile("" : "+s"(b.mult), "+s"(b.noise), "+s"(b.trec), "+s"(b.tidx), "+s"(b.wt) : : "memory");
+    tm_eval_body<KU, GRAD>(b, chain, 0, s_dyn + f.p_doubles);
+}
+
+template <int KU>
+static int tm_launch_fused_k(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
+{
+    const int Smax = a.tile_big > a.tile_small ? a.tile_big : a.tile_small;
+    const size_t lds = ((size_t)f.p_doubles + (grad ? (size_t)TM_THREADS * KU * Smax : 1)) * sizeof(double);
+    if (lds > 48 * 1024) {
+        const void *fn = grad ? reinterpret_cast<const void *>(tamcmc_fused_kernel<KU, true>)
+                              : reinterpret_cast<const void *>(tamcmc_fused_kernel<KU, false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (grad) hipLaunchKernelGGL((tamcmc_fused_kernel<KU, true>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a);
+    else      hipLaunchKernelGGL((tamcmc_fused_kernel<KU, false>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a);
+    return (int)hipGetLastError();
+}
+
+int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream)
+{
+    if (a.n_mult > TM_MAXMULT || a.tiles != 1) return (int)hipErrorInvalidValue;
+    switch (KU) {
+    case 1: return tm_launch_fused_k<1>(L, f, a, Nchains, grad, (hipStream_t)stream);
+    case 2: return tm_launch_fused_k<2>(L, f, a, Nchains, grad, (hipStream_t)stream);
+    case 4: return tm_launch_fused_k<4>(L, f, a, Nchains, grad, (hipStream_t)stream);
+    default: return (int)hipErrorInvalidValue;
+    }
+}

@@ -7,7 +7,7 @@
 // evaluation on one stream (or in one hipGraph) without a host round trip.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
-#include "tamcmc_derive.h"
+#include "tamcmc_setup_body.h"
 
 #define TM_SETUP_THREADS 192   // wave 0: multiplets; wave 1: noise record + tile polynomials; wave 2: m-ratios -- concurrently
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
@@ -18,220 +18,9 @@ __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout
                                                           TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
                                                           double *__restrict__ hser, int32_t *__restrict__ order)
 {
-    __shared__ int s_win[TM_MAXMULT][3];   // truncation windows and component counts, for the per-tile active lists
-    __shared__ __attribute__((aligned(16))) int s_cost[TM_ORDER_MAX + 4];
-    const int chain = blockIdx.x;
-    const int tid = threadIdx.x;
     extern __shared__ double s_p[];   // this chain's params row: every later access is an LDS read
-    double *p = s_p;
-    for (int e = tid; e < L.Nparams; e += TM_SETUP_THREADS) p[e] = params[(size_t)chain * L.Nparams + e];
-    // the caller's temperature array may live in host memory: read it once, now (latency hidden behind the work below)
-    const double Tc = (tid == 64) ? Tcoefs[chain] : 1.0;
-    __shared__ TmChain C;
-    __shared__ int s_status;
-    __syncthreads();
-#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 1
-    return;   // timing-only build
-#endif
-
-    if (tid == 0) s_status = 0;
-    // phase 1: the chain's scalars (one lane); everything below needs them
-    if (L.family != TM_FAM_GAUSS && tid == 0) {
-#if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))   // timing-only build: no chain-level derivation
-        tm_derive_chain_scalars(L, p, C);
-#endif
-    }
-    __syncthreads();
-    // phase 2, three waves side by side: wave 2 the m-ratios from the inclination, wave 1 the noise record and the
-    // tile polynomials, wave 0 every multiplet's record up to the products with those ratios
-    if (L.family != TM_FAM_GAUSS && tid >= 128) {
-#if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))
-        tm_derive_chain_ratios(L, C, tid - 128);
-#endif
-    }
-
-    __shared__ TmNoise s_N;           // N.H[N.nh] is dynamically indexed: LDS, not scratch
-    if (tid == 64) {
-        TmNoise &N = s_N;
-        for (int k = 0; k < TM_MAXH; k++) { N.H[k] = 0.0; N.lt[k] = 0.0; N.p[k] = 0.0; }
-        N.N0 = 0.0; N.gA = 0.0; N.gnu0 = 0.0; N.gs2 = 1.0; N.nh = 0; N.has_gauss = 0; N.pad = 0;
-        int z = L.z, Nnoise = L.Nnoise, nharvey = L.nharvey;
-        bool take_abs = true;
-        if (L.model_case == 0) {
-            // model_Test_Gaussian, models.cpp:2021-2034 (no abs anywhere)
-            N.has_gauss = 1; N.gA = p[0]; N.gnu0 = p[2]; N.gs2 = p[1] * p[1];
-            z = 3; Nnoise = 1; nharvey = 0; take_abs = false;
-        } else if (L.model_case == 1) {
-            // model_Harvey_Gaussian, models.cpp:1968-1992
-            N.has_gauss = 1; N.gA = fabs(p[0]); N.gnu0 = p[2]; N.gs2 = fabs(p[1]) * fabs(p[1]);
-            z = 3; Nnoise = 4; nharvey = 1;
-        }
-        double extra = 0.0;
-        for (int k = 0; k < nharvey; k++) {
-            const double H = fabs(p[z + 3 * k]), tau = fabs(p[z + 3 * k + 1]), pw = fabs(p[z + 3 * k + 2]);
-            if (tau != 0) {                           // noise_models.cpp:31
-                if (pw == 0) { extra = extra + H * 0.5; continue; } // (..)^0 = 1 for every bin
-                N.H[N.nh] = H; N.lt[N.nh] = log((1e-3) * tau); N.p[N.nh] = pw; N.nh++;
-            }
-        }
-        const double n0 = p[z + Nnoise - 1];
-        N.N0 = (take_abs ? fabs(n0) : n0) + extra;
-    }
-    if (tid >= 64 && tid < 128) {
-        // Wave 1, concurrently with wave 0's multiplet derivation: the Harvey background of every tile as Taylor
-        // polynomials in z = p (log x - log x_c).  u(z) = 1/(1 + t0 e^z) is analytic for |z| < pi (nearest pole at
-        // ln(1/t0) + i pi), so for |z| <= 0.04 the series truncated at degree 8 is exact to (0.04/pi)^9 ~ 1e-17.
-        // Coefficients by the power-series reciprocal of D(z) = 1 + t0 sum z^j/j!.
-        // s_N was written by lane 0 of THIS wave: LDS operations of one wave complete in order.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 1)   // timing-only build: no tile polynomials
-        for (int tile = tiles; tile < tiles; tile += 64) {
-#else
-        for (int tile = tid - 64; tile < tiles; tile += 64) {
-#endif
-            const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
-            TmTileRec R;
-            R.nact = 0;
-            int ic = base + TB / 2; if (ic > L.Nx - 1) ic = L.Nx - 1;
-            int i1 = base + TB - 1; if (i1 > L.Nx - 1) i1 = L.Nx - 1;
-            const double lx_c = lx[ic], lx_0 = lx[base], lx_1 = lx[i1];
-            const double span = fmax(fabs(lx_0 - lx_c), fabs(lx_1 - lx_c));
-            bool ok = (span == span) && (lx_c - lx_c == 0.0) && (L.bg_exact == 0);
-            R.lxc = lx_c;
-#pragma unroll
-            for (int j = 0; j <= TM_PDEG; j++) R.bg[j] = 0.0;
-            R.bg[0] = s_N.N0;
-#pragma unroll
-            for (int h = 0; h < TM_MAXH; h++) {
-                R.t0[h] = 0.0;
-                if (h < s_N.nh) {
-                    const double ph = s_N.p[h], Hh = s_N.H[h];
-                    ok = ok && (ph * span <= 0.04);
-                    const double t0 = exp(ph * (s_N.lt[h] + lx_c));
-                    ok = ok && (t0 < 1e290);
-                    R.t0[h] = t0;
-                    // one degree more than the model polynomial uses: the gradient path differentiates the series
-                    const double ifac[TM_HSER] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880};
-                    double d[TM_HSER], u[TM_HSER];
-                    d[0] = 1.0 + t0;
-#pragma unroll
-                    for (int j = 1; j < TM_HSER; j++) d[j] = t0 * ifac[j];
-                    const double id0 = 1.0 / d[0];
-                    u[0] = id0;
-#pragma unroll
-                    for (int j = 1; j < TM_HSER; j++) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int i = 1; i <= j; i++) acc = acc + d[i] * u[j - i];
-                        u[j] = -id0 * acc;
-                    }
-                    double pj = 1.0;
-                    double *hs = (hser != nullptr) ? hser + (((size_t)chain * tiles + tile) * TM_MAXH + h) * TM_HSER : nullptr;
-#pragma unroll
-                    for (int j = 0; j < TM_HSER; j++) {
-                        const double cj = u[j] * pj;                 // coefficient of (log x - lxc)^j in u_h
-                        if (j <= TM_PDEG) R.bg[j] = R.bg[j] + Hh * cj;
-                        if (hs != nullptr) hs[j] = cj;
-                        pj = pj * ph;
-                    }
-                }
-            }
-            R.npoly = ok ? 1 : 0;
-            trec[(size_t)chain * tiles + tile] = R;    // nact is filled in below, once the windows are known
-        }
-    }
-
-    // wave 0: lane j derives multiplet j up to the ratio products, waits for the ratios, finishes it; chains with more
-    // than 64 multiplets do the rest afterwards in one go
-    TmMultFull M;        // in registers: every array index inside is a compile-time constant
-#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 2)   // timing-only build: no multiplet derivation
-    const int n_mult = 0;
-#else
-    const int n_mult = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
-#endif
-    const bool first = tid < 64 && tid < n_mult;
-    if (first) tm_derive_mult_pre(L, C, p, tid, M);
-    __syncthreads();     // ratios (wave 2) and the chain record are complete
-    if (L.family != TM_FAM_GAUSS && chain_rec != nullptr)   // keep the chain record for the backward kernel (gradient path)
-        for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_SETUP_THREADS)
-            reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
-    if (tid < 64) {
-        for (int j = tid; j < n_mult; j += 64) {
-            if (j == tid) { if (first) tm_mult_apply_ratios(L, C, M); }
-            else tm_derive_mult(L, C, p, j, M);
-            TmMult out;
-            const double g2 = M.W * M.W;
-            out.g2 = g2;
-            if (C.asym == 0) {
-                out.aA = 0.0; out.aB = 1.0; out.c2 = 0.0; out.has_asym = 0;
-            } else {
-                // A(x) = (1 + asym (x/f - 1))^2 + (0.5 Gamma asym / f)^2, build_lorentzian.cpp:96
-                const double cc = 0.5 * M.W * C.asym / M.f;
-                out.aA = C.asym / M.f; out.aB = 1.0 - C.asym; out.c2 = cc * cc; out.has_asym = 1;
-            }
-#pragma unroll
-            for (int k = 0; k < TM_MAXM; k++) {
-                if (k < M.ncomp) { out.nu2[k] = 2.0 * M.nu[k]; out.hq[k] = M.h[k] * g2; }
-                else             { out.nu2[k] = 0.0;           out.hq[k] = 0.0; }
-            }
-            out.imin = M.imin; out.imax = M.imax; out.ncomp = M.ncomp;
-            s_win[j][0] = M.imin; s_win[j][1] = M.imax; s_win[j][2] = M.ncomp;
-            if (M.status != 0) atomicMax(&s_status, M.status);
-            mult[(size_t)chain * L.n_mult + j] = out;
-            if (aux != nullptr) aux[(size_t)chain * L.n_mult + j] = M;
-        }
-    }
-    __syncthreads();
-#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
-    return;   // timing-only build
-#endif
-    if (tid == 64) {
-        s_N.status = s_status;
-        wt[2 * chain] = Tc;                  // device copy for the eval / backward kernels
-        wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
-        noise[chain] = s_N;
-    }
-
-    // ---------------- active multiplet lists: one thread per tile ----------------
-    // the multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel)
-    const int nm = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
-    for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) {
-        const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
-        int32_t *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
-        int nact = 0, cost = 0;
-        for (int j = 0; j < nm; j++)
-            if (s_win[j][0] < base + TB && s_win[j][1] > base) {
-                ti[nact++] = j;
-                const int lo = s_win[j][0] > base ? s_win[j][0] : base, hi = s_win[j][1] < base + TB ? s_win[j][1] : base + TB;
-                cost += (s_win[j][2] + 2) * ((hi - lo + 255) >> 8);     // ~ component evaluations, in units of 256 bins
-            }
-        trec[(size_t)chain * tiles + tile].nact = nact;
-        // unique key: cost first, lower tile index first among equals
-        if (tile < TM_ORDER_MAX) s_cost[tile] = ((cost < (1 << 20) ? cost : (1 << 20)) << 10) + (TM_ORDER_MAX - 1 - tile);
-    }
-    // launch order of this chain's tiles: costliest first (rank = number of tiles with a larger key)
-    if (order != nullptr) {
-        if (tiles <= TM_ORDER_MAX) {
-            if (tid < 4) s_cost[tiles + tid] = -1;            // padding for the 4-wide reads below: never "costs more"
-            __syncthreads();
-            for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) {
-                const int c = s_cost[tile];
-                int r = 0;
-#pragma unroll 4
-                for (int t2 = 0; t2 < tiles; t2 += 4) {
-                    const int4 c4 = *reinterpret_cast<const int4 *>(&s_cost[t2]);
-                    r += (c4.x > c) ? 1 : 0;
-                    r += (c4.y > c) ? 1 : 0;
-                    r += (c4.z > c) ? 1 : 0;
-                    r += (c4.w > c) ? 1 : 0;
-                }
-                order[(size_t)chain * tiles + r] = tile;
-            }
-        } else {
-            for (int tile = tid; tile < tiles; tile += TM_SETUP_THREADS) order[(size_t)chain * tiles + tile] = tile;
-        }
-    }
+    tm_setup_body<TM_SETUP_THREADS>(L, (int)blockIdx.x, params, Tcoefs, wt, lx, UB, units, big, small, tiles, mult, noise, trec, tidx,
+                                    chain_rec, aux, hser, order, s_p);
 }
 
 int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,

@@ -332,3 +332,28 @@ def test_more_than_64_multiplets(accel_mod, orc):
     assert np.max(np.abs(gp[0] - gfd)) <= 2e-4 * np.max(np.abs(gfd))       # windows are on (trunc_c = 20): FD sees their edges
     cols = [int(np.flatnonzero(idx == v)[0]) for v in pick]
     assert np.array_equal(gp[0], g[0][cols])
+
+
+@pytest.mark.parametrize("Nx", [973, 2048, 400])
+def test_fused_small_grid_launch_equals_two_launches(accel_mod, orc, monkeypatch, Nx):
+    """Grids of <= 2048 bins are one tile per chain, and the prologue and the evaluation then share a launch
+    (tamcmc_fused.hip).  Same code, same arithmetic: bit-identical to the two-launch path (TAMCMC_FUSED=0)."""
+    w = W.any_model(11, Nx=Nx, trunc_c=20.0)
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 7, scale=0.002, seed=3)
+    T = synth.temperatures(7)
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TAMCMC_FUSED", fused)
+        with accel_mod.Accel(11, w["plength"], w["x"], y) as acc:
+            assert acc.geometry()["tiles"] == 1
+            acc.set_vars(w["index_to_relax"])
+            L, st = acc.eval_batch(P, T)
+            Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        res.append((L, st, Lg, stg, g))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    rL, rst = orc.generate_batch(11, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(res[0][1], rst)
+    check_logL(res[0][0], rL)
+    check_logL(res[0][2], rL)
