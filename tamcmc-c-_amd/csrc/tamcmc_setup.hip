@@ -1,10 +1,11 @@
-// tamcmc_setup.hip -- per-chain prologue kernel: params row -> multiplet table + noise terms.
-// Compiled with -ffp-contract=off (see tamcmc_derive.h).
+// tamcmc_setup.hip -- per-chain prologue kernel: params row -> multiplet table, noise record, tile descriptors,
+// active-multiplet lists and launch ranks.  Compiled with -ffp-contract=off (see tamcmc_derive.h); the body lives in
+// tamcmc_setup_body.h, which the fused small-grid kernel (tamcmc_fused.hip) shares.
 //
-// One workgroup (one wave of 64) per chain.  Lane 0 derives the chain-level quantities into LDS,
-// then lanes stride over the chain's multiplets.  The work is O(Nparams) per chain (microseconds);
-// it exists as a kernel so that a sampler can keep params resident in HBM and chain the whole
-// evaluation on one stream (or in one hipGraph) without a host round trip.
+// One workgroup of three waves per chain: one lane derives the chain's scalars, then wave 0 derives the multiplets,
+// wave 1 the noise record and the per-tile background polynomials, wave 2 the m-ratios, side by side.  The work is
+// O(Nparams) per chain (microseconds); it exists as a kernel so that a sampler can keep params resident in HBM and
+// chain the whole evaluation on one stream without a host round trip.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
 #include "tamcmc_setup_body.h"
