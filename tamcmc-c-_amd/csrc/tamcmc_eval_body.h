@@ -574,11 +574,24 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
 #if defined(TM_ABLATE) && (TM_ABLATE & 4)    // timing-only build: plain stores, no ticket, no finalize
             pp[2 * tile] = t1; pp[2 * tile + 1] = t2;
 #else
+            if (a.tiles == 1) {
+                // the chain's only tile: nothing to hand over.  Same value as the general path below, which would add
+                // zeros to t1 and t2 (the other lanes' empty strides), without its store-drain-ticket-reload round trip
+                pp[0] = t1; pp[1] = t2;
+                double f = (a.likelihood_case == 0) ? -a.like_p * (t1 + t2) : -t1;
+                f = f / a.wt[2 * chain];
+                int st = a.noise[chain].status;
+                if (st != 0) f = __builtin_nan("");
+                else if (!(f == f)) st = 1;
+                a.logL[chain] = f;
+                if (a.status) a.status[chain] = st;
+            } else {
             __hip_atomic_store(pp + 2 * tile, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(pp + 2 * tile + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int prev = __hip_atomic_fetch_add(a.ticket + chain, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (prev == a.tiles - 1) ? 1 : 0;
+            }
 #endif
         }
         last = __shfl(last, 0, 64);
