@@ -47,7 +47,7 @@ struct tamcmc_ctx {
     int cap = 0;
     bool cap_grad = false;
     double *d_params = nullptr, *d_T = nullptr, *d_logL = nullptr, *d_part = nullptr;
-    double *d_gmult = nullptr, *d_gnoise = nullptr, *d_grad = nullptr, *d_hser = nullptr;
+    double *d_gmult = nullptr, *d_gnoise = nullptr, *d_hser = nullptr;
     int32_t *d_order = nullptr; int order_mode = 2;
     int fuse = 1;                  // one tile per chain -> prologue and evaluation in one launch (TAMCMC_FUSED=0 disables)
     int32_t *d_status = nullptr, *d_rows = nullptr;
@@ -162,13 +162,13 @@ static int build_layout(TmLayout &L, int model_case, int likelihood_case, double
 static void free_batch(tamcmc_ctx *c)
 {
     (void)hipFree(c->d_params); (void)hipFree(c->d_T); (void)hipFree(c->d_logL); (void)hipFree(c->d_part);
-    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_grad); (void)hipFree(c->d_hser); (void)hipFree(c->d_order); c->d_order = nullptr;
+    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_hser); (void)hipFree(c->d_order); c->d_order = nullptr;
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
     (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
     (void)hipFree(c->d_ticket); c->d_ticket = nullptr;
     (void)hipFree(c->d_wt); c->d_wt = nullptr;
-    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_grad = c->d_hser = nullptr;
+    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_hser = nullptr;
     c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
     c->cap = 0; c->cap_grad = false;
 }
@@ -200,8 +200,6 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
         TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g_cap * nm * TM_GSLOTS * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g_cap * TM_NSLOTS * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_hser, n * c->tiles_g_cap * TM_MAXH * TM_HSER * sizeof(double)));
-        const int nv = c->Nvars > 0 ? c->Nvars : 1;
-        TM_HIP(hipMalloc(&c->d_grad, n * nv * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_chain_rec, n * tm_sizeof_chain_rec()));
         TM_HIP(hipMalloc(&c->d_aux, n * nm * tm_sizeof_aux()));
     }
@@ -319,12 +317,10 @@ extern "C" int tamcmc_ctx_set_vars(tamcmc_ctx *c, int32_t Nvars, const int32_t *
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_relax); c->d_relax = nullptr;
-    (void)hipFree(c->d_grad); c->d_grad = nullptr;
     c->Nvars = Nvars;
     if (Nvars > 0) {
         TM_HIP(hipMalloc(&c->d_relax, (size_t)Nvars * sizeof(int32_t)));
         TM_HIP(hipMemcpy(c->d_relax, index_to_relax, (size_t)Nvars * sizeof(int32_t), hipMemcpyHostToDevice));
-        if (c->cap > 0 && c->cap_grad) TM_HIP(hipMalloc(&c->d_grad, (size_t)c->cap * Nvars * sizeof(double)));
     }
     return TAMCMC_OK;
 }
@@ -589,10 +585,10 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
         d_rows = c->d_rows;
     }
     // logL / status (a few hundred bytes) are written straight into the mapped host buffer by the last kernel; the
-    // gradient block goes through device memory and one copy (scattered 8-byte stores over PCIe are slow)
-    rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, grad ? c->d_grad : nullptr, dv_status, d_rows, c->d_model);
+    // the backward kernel writes each chain's gradient row as one run of consecutive stores, straight into the mapped
+    // host buffer (a copy-engine transfer of these ~20 KB would add ~20 us of latency)
+    rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, grad ? dv_out + n : nullptr, dv_status, d_rows, c->d_model);
     if (rc != TAMCMC_OK) return rc;
-    if (grad) TM_HIP(hipMemcpyAsync(c->h_out + n, c->d_grad, n * (size_t)c->Nvars * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (n_rows > 0) {
         // rows whose chain was listed more than once share one device row
         for (int r = 0; r < n_rows; r++) {

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     // dynamic LDS carve-up: the chain's params row first (every later access is an LDS read)
     double *p = s_dyn;                                         // [Nparams]
     for (int e = tid; e < L.Nparams; e += TM_BW_THREADS) p[e] = params[(size_t)chain * L.Nparams + e];
-    double *pair_val = s_dyn + L.Nparams;                      // [nm*TM_NPAIR + ncp]
+    double *s_row = s_dyn + L.Nparams;                         // [Nvars] this chain's gradient row, written out coalesced
+    double *pair_val = s_row + Nvars;                          // [nm*TM_NPAIR + ncp]
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
@@ -473,9 +474,13 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                 for (int q = 0; q < 8; q++) acc += (id[q] == target) ? v[q] : 0.0;
             }
             const double a1 = __shfl_down(acc, 1, 4), a2 = __shfl_down(acc, 2, 4), a3 = __shfl_down(acc, 3, 4);
-            if (seg == 0 && k < Nvars) grad[(size_t)chain * Nvars + k] = ((acc + a1) + a2) + a3;
+            if (seg == 0 && k < Nvars) s_row[k] = ((acc + a1) + a2) + a3;
         }
     }
+    // the row leaves as consecutive 8-byte stores of consecutive lanes: the caller's buffer may be host memory mapped
+    // over PCIe, where a scattered store is a transaction of its own
+    __syncthreads();
+    for (int k = tid; k < Nvars; k += TM_BW_THREADS) grad[(size_t)chain * Nvars + k] = s_row[k];
 }
 
 int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units, int big, int small, const double *d_params,
@@ -488,7 +493,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units,
     const int nm = L.n_mult;
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
-    size_t lds = (size_t)L.Nparams * sizeof(double) + (size_t)npairs_max * sizeof(double) +
+    size_t lds = ((size_t)L.Nparams + (size_t)Nvars) * sizeof(double) + (size_t)npairs_max * sizeof(double) +
                  (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + (size_t)((npairs_max + 1) & ~1) * sizeof(int);
     const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);
     const int aux_in_lds = (lds + aux_bytes <= 100 * 1024) ? 1 : 0;
