@@ -10,6 +10,7 @@
 //   hser[Nchains][tiles][TM_MAXH][TM_HSER] : per-profile series of u = 1/(1+t) in (log x - lxc), gradient path only
 //   logL[Nchains], status[Nchains] (int32), grad[Nchains][Nvars]
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #define TM_MAXM 7      // components of a multiplet: 2l+1, l <= 3 (build_lorentzian.cpp:74)

@@ -84,3 +84,12 @@ def test_synthetic_generator_is_deterministic(accel_mod):
     assert w4["params_true"].size == 106
     w1 = synth.workload_c1()
     assert w1["model_case"] == 11 and w1["x"].size == 10000
+
+
+def test_tile_geometry_partitions_the_grid():
+    """TM_TILE_U0 / TM_TILE_S / tm_tile_count (two alternating tile sizes): every sub-block belongs to exactly one tile."""
+    import subprocess
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.run(["make", "-C", cpp, "-s", "geometry_check"], check=True)
+    r = subprocess.run([os.path.join(cpp, "geometry_check")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
