@@ -1,0 +1,60 @@
+"""Randomized HIP-vs-oracle parity sweep: model id, grid length (2 ... 60000 bins: fused one-tile launches, short-grid
+tiles, full-size tiles), truncation constant, asymmetry, amplitude mode, likelihood, chain count and parameter scatter
+are drawn at random.  60 cases by default; TAMCMC_FUZZ_CASES / TAMCMC_FUZZ_SEED widen the sweep."""
+import os
+
+import numpy as np
+import pytest
+
+import workloads as W
+from tamcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_configurations_match_the_oracle(accel_mod, orc):
+    ncases = int(os.environ.get("TAMCMC_FUZZ_CASES", "60"))
+    rng = np.random.default_rng(int(os.environ.get("TAMCMC_FUZZ_SEED", "1")))
+    worst_L = worst_M = 0.0
+    done, failures = 0, []
+    for case in range(ncases):
+        mid = int(rng.choice(W.ALL_IDS))
+        Nx = int(rng.choice([rng.integers(2, 600), rng.integers(600, 2100), rng.integers(2100, 12000), rng.integers(12000, 60000)]))
+        kw = dict(Nx=Nx)
+        if mid not in (0, 1):
+            kw.update(trunc_c=float(rng.choice([3.0, 7.0, 20.0, 50.0, 10000.0])), asym=float(rng.choice([0.0, 0.0, 25.0, -40.0, 5.0])),
+                      do_amp=bool(rng.integers(0, 2)))
+        w = W.any_model(mid, **kw)
+        m, st0 = orc.model(mid, w["params_true"], w["plength"], w["x"])
+        if st0 != 0 or not np.all(np.isfinite(m)) or np.any(m <= 0):
+            continue                                  # not a usable truth spectrum (e.g. 2 bins and an empty window)
+        y = synth.make_spectrum(m, seed=int(rng.integers(1, 1 << 30)))
+        n = int(rng.integers(1, 9))
+        P = W.perturbed(w, n, scale=float(rng.choice([0.0005, 0.003, 0.01])), seed=int(rng.integers(1, 1 << 30)))
+        T = synth.temperatures(n) if n > 1 else np.ones(1)
+        like = int(rng.integers(0, 2)) if mid in (0, 1, 2, 11) else 0
+        sig = 0.05 + 0.2 * np.abs(np.sin(np.arange(y.size))) if like == 1 else None
+        row = int(rng.integers(0, n))
+        with accel_mod.Accel(mid, w["plength"], w["x"], y, sigma_y=sig, likelihood_case=like) as acc:
+            acc.set_vars(w["index_to_relax"])
+            L, st, models = acc.eval_batch(P, T, model_rows=[row])
+            Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        rL, rst, rm = orc.generate_batch(mid, w["plength"], w["x"], y, P, T, sigma_y=sig, likelihood_case=like, want_models=True)
+        ok = np.array_equal(st, rst) and np.array_equal(stg, rst)
+        good = (rst == 0) & np.isfinite(rL)
+        if np.any(good):
+            eL = float(np.max(np.abs(L[good] - rL[good]) / np.abs(rL[good])))
+            eG = float(np.max(np.abs(Lg[good] - rL[good]) / np.abs(rL[good])))
+            worst_L = max(worst_L, eL, eG)
+            ok = ok and eL <= 1e-10 and eG <= 1e-10 and bool(np.all(np.isfinite(g[good])))
+            if good[row]:
+                eM = float(np.max(np.abs(models[0] - rm[row]) / np.abs(rm[row])))
+                worst_M = max(worst_M, eM)
+                ok = ok and eM <= 1e-12
+        ok = ok and bool(np.all(np.isnan(L[~good]) == np.isnan(rL[~good])))
+        done += 1
+        if not ok:
+            failures.append((case, mid, kw, n, like, st.tolist(), rst.tolist()))
+    print(f"fuzz: {done} cases, worst relative logL error {worst_L:.2e}, model {worst_M:.2e}")
+    assert not failures, failures
+    assert done >= ncases // 2
