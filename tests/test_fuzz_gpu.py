@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 def test_random_configurations_match_the_oracle(accel_mod, orc):
     ncases = int(os.environ.get("TAMCMC_FUZZ_CASES", "60"))
     rng = np.random.default_rng(int(os.environ.get("TAMCMC_FUZZ_SEED", "1")))
-    worst_L = worst_M = 0.0
+    worst_L = worst_M = worst_g = 0.0
     done, failures = 0, []
+    fd_done, fd_max = 0, max(8, ncases // 10)
     for case in range(ncases):
         mid = int(rng.choice(W.ALL_IDS))
         Nx = int(rng.choice([rng.integers(2, 600), rng.integers(600, 2100), rng.integers(2100, 12000), rng.integers(12000, 60000)]))
@@ -52,9 +53,20 @@ def test_random_configurations_match_the_oracle(accel_mod, orc):
                 worst_M = max(worst_M, eM)
                 ok = ok and eM <= 1e-12
         ok = ok and bool(np.all(np.isnan(L[~good]) == np.isnan(rL[~good])))
+        # gradient against Richardson-extrapolated central differences of the oracle, where logL is smooth (no
+        # truncation window) and the grid is short enough for ~100 oracle evaluations
+        if ok and good[0] and kw.get("trunc_c") == 10000.0 and Nx <= 3000 and fd_done < fd_max:
+            gfd, st2 = orc.grad_fd(mid, w["plength"], w["x"], y, P[0], T[0], w["index_to_relax"], rel_step=1e-6, sigma_y=sig,
+                                   likelihood_case=like)
+            if st2 == 0 and np.all(np.isfinite(gfd)):
+                eg = float(np.max(np.abs(g[0] - gfd)) / np.max(np.abs(gfd)))
+                worst_g = max(worst_g, eg)
+                ok = ok and eg <= 2e-5
+                fd_done += 1
         done += 1
         if not ok:
             failures.append((case, mid, kw, n, like, st.tolist(), rst.tolist()))
-    print(f"fuzz: {done} cases, worst relative logL error {worst_L:.2e}, model {worst_M:.2e}")
+    print(f"fuzz: {done} cases, worst relative logL error {worst_L:.2e}, model {worst_M:.2e}; {fd_done} gradients against "
+          f"finite differences, worst {worst_g:.2e} of the largest entry")
     assert not failures, failures
     assert done >= ncases // 2
