@@ -65,6 +65,8 @@ struct tamcmc_ctx {
     double *h_in = nullptr, *h_out = nullptr;
     int32_t *h_status = nullptr;
     int h_cap = 0, h_nvars = -1;
+    double *dv_in = nullptr, *dv_out = nullptr;   // device views of h_in / h_out / h_status (looked up once per allocation)
+    int32_t *dv_status = nullptr;
     hipEvent_t ev_done = nullptr;  // completion of a host-pointer call, polled (see wait_done)
     int in_flight = 0;             // chains of a tamcmc_eval_batch_begin not yet collected by _end
     // variables
@@ -485,6 +487,40 @@ static int wait_done(tamcmc_ctx *c)
     }
 }
 
+// Host path without model rows: instead of waiting for the launch to retire, watch the results arrive.  Every logL and
+// gradient entry is one aligned 8-byte store and every status one 4-byte store into coherent pinned memory, written
+// exactly once per launch, so a slot that no longer holds the marker put there before the launch holds its final
+// value -- no ordering between slots is assumed.  (A kernel NaN never has this payload.)  The completion event is still
+// recorded and consulted now and then, so that a failed launch ends the wait with an error instead of a hang.
+static const uint64_t TM_PENDING_BITS = 0x7FF8DEADBEEF5A5AULL;
+// nw = doubles to watch in h_out: n (logL) or n * (1 + Nvars) (logL, then the gradient rows)
+static void mark_pending(tamcmc_ctx *c, int n, size_t nw)
+{
+    uint64_t *o = reinterpret_cast<uint64_t *>(c->h_out);
+    for (size_t m = 0; m < nw; m++) o[m] = TM_PENDING_BITS;
+    for (int m = 0; m < n; m++) c->h_status[m] = -1;
+}
+static int wait_data(tamcmc_ctx *c, int n, size_t nw)
+{
+    volatile const uint64_t *o = reinterpret_cast<volatile const uint64_t *>(c->h_out);
+    volatile const int32_t *st = c->h_status;
+    unsigned spins = 0;
+    for (size_t m = 0; m < nw;) {
+        if (o[m] != TM_PENDING_BITS && (m >= (size_t)n || st[m] != -1)) { m++; continue; }
+        __builtin_ia32_pause();
+        if ((++spins & 2047u) == 0) {
+            const hipError_t e = hipEventQuery(c->ev_done);
+            if (e == hipSuccess) {
+                if (o[m] != TM_PENDING_BITS && (m >= (size_t)n || st[m] != -1)) continue;
+                snprintf(g_hip_err, sizeof(g_hip_err), "launch retired without writing result slot %zu", m);
+                return TAMCMC_E_HIP;
+            }
+            if (e != hipErrorNotReady) { snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e)); return TAMCMC_E_HIP; }
+        }
+    }
+    return TAMCMC_OK;
+}
+
 // pinned, device-mapped staging of the host-pointer entry points
 static int ensure_staging(tamcmc_ctx *c, int Nchains)
 {
@@ -498,6 +534,9 @@ static int ensure_staging(tamcmc_ctx *c, int Nchains)
     TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), cap * ((size_t)Nparams + 1) * sizeof(double), flags));
     TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_out), cap * ((size_t)(c->Nvars > 0 ? c->Nvars : 0) + 1) * sizeof(double), flags));
     TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_status), cap * sizeof(int32_t), flags));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dv_in), c->h_in, 0));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dv_out), c->h_out, 0));
+    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dv_status), c->h_status, 0));
     c->h_cap = (int)cap; c->h_nvars = c->Nvars;
     return TAMCMC_OK;
 }
@@ -515,9 +554,8 @@ extern "C" int tamcmc_eval_batch_begin(tamcmc_ctx *c, int32_t Nchains, int32_t N
     std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
     double *dv_in = nullptr, *dv_out = nullptr;
     int32_t *dv_status = nullptr;
-    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_in), c->h_in, 0));
-    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_out), c->h_out, 0));
-    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_status), c->h_status, 0));
+    dv_in = c->dv_in; dv_out = c->dv_out; dv_status = c->dv_status;
+    mark_pending(c, Nchains, (size_t)Nchains);
     rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, nullptr, dv_status, nullptr, nullptr);
     if (rc != TAMCMC_OK) return rc;
     if (!c->ev_done) TM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
@@ -530,13 +568,7 @@ extern "C" int tamcmc_eval_batch_end(tamcmc_ctx *c, int32_t Nchains, double *log
 {
     if (!c || !logL || c->in_flight != Nchains) return TAMCMC_E_INVALID;
     c->in_flight = 0;
-    for (;;) {
-        const hipError_t e = hipEventQuery(c->ev_done);
-        if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) { snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e)); return TAMCMC_E_HIP; }
-        __builtin_ia32_pause();
-    }
-    TM_HIP(hipGetLastError());
+    { const int rc = wait_data(c, Nchains, (size_t)Nchains); if (rc != TAMCMC_OK) return rc; }
     std::memcpy(logL, c->h_out, (size_t)Nchains * sizeof(double));
     if (status) std::memcpy(status, c->h_status, (size_t)Nchains * sizeof(int32_t));
     return TAMCMC_OK;
@@ -566,9 +598,7 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
     double *dv_in = nullptr, *dv_out = nullptr;
     int32_t *dv_status = nullptr;
-    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_in), c->h_in, 0));
-    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_out), c->h_out, 0));
-    TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dv_status), c->h_status, 0));
+    dv_in = c->dv_in; dv_out = c->dv_out; dv_status = c->dv_status;
     const int32_t *d_rows = nullptr;
     if (n_rows > 0) {
         std::vector<int32_t> rows(n, -1);
@@ -587,6 +617,9 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     // logL / status (a few hundred bytes) are written straight into the mapped host buffer by the last kernel; the
     // the backward kernel writes each chain's gradient row as one run of consecutive stores, straight into the mapped
     // host buffer (a copy-engine transfer of these ~20 KB would add ~20 us of latency)
+    const bool watch = (n_rows == 0);                         // no model rows to copy back: watch the results arrive (wait_data)
+    const size_t nwatch = n * (grad ? (size_t)c->Nvars + 1 : 1);
+    if (watch) mark_pending(c, Nchains, nwatch);
     rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, grad ? dv_out + n : nullptr, dv_status, d_rows, c->d_model);
     if (rc != TAMCMC_OK) return rc;
     if (n_rows > 0) {
@@ -598,7 +631,13 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
                                   (size_t)c->L.Nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
     }
-    rc = wait_done(c);
+    if (watch) {
+        if (!c->ev_done) TM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        TM_HIP(hipEventRecord(c->ev_done, c->stream));
+        rc = wait_data(c, Nchains, nwatch);
+    } else {
+        rc = wait_done(c);
+    }
     if (rc != TAMCMC_OK) return rc;
     TM_HIP(hipGetLastError());
     std::memcpy(logL, c->h_out, n * sizeof(double));
