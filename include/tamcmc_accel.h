@@ -97,7 +97,10 @@ int tamcmc_eval_batch_device(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams,
 
 /* tamcmc_eval_batch split in two for callers that have host work to overlap with the GPU (the sampler draws the next
  * iteration's random numbers meanwhile): _begin copies params / Tcoefs and enqueues the likelihood evaluation, _end
- * waits and delivers logL / status.  Likelihood only (no gradient, no model rows); one batch in flight per ctx. */
+ * waits and delivers logL / status.  Likelihood only (no gradient, no model rows); one batch in flight per ctx.
+ * Both host-pointer entry points return as soon as every result has arrived in the library's pinned staging buffer,
+ * which can be a few microseconds before the launch itself retires on the ctx stream; everything else in this API
+ * that touches the ctx is ordered after it on that stream (or synchronises it). */
 int tamcmc_eval_batch_begin(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs);
 int tamcmc_eval_batch_end(tamcmc_ctx *ctx, int32_t Nchains, double *logL, int32_t *status);
 
