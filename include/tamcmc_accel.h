@@ -73,6 +73,16 @@ int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case, int likel
  * the free variables; needed only for gradients.  grad column k = d(logL/T)/d params[index_to_relax[k]]. */
 int tamcmc_ctx_set_vars(tamcmc_ctx *ctx, int32_t Nvars, const int32_t *index_to_relax);
 
+/* Extension (no counterpart in the reference, which fits one spectrum per process): several spectra ON THE SAME GRID
+ * and model layout in one context -- an ensemble of synthetic stars, noise realisations of one star -- so that their
+ * chains share a batch (one launch at the full-batch rate; separate contexts on separate streams overlap only ~1.5x,
+ * DESIGN.md section 6).  set_spectra replaces the resident spectrum by Nspectra blocks of Nx (sigma_y likewise, NULL
+ * unless the likelihood is chi_square) and clears the map; set_chain_spectrum says which spectrum chain m of the
+ * following batches is fitted to (batches longer than the map, or no map, use spectrum 0 for every chain).  A chain's
+ * result is bit for bit what a context holding only its spectrum returns. */
+int tamcmc_ctx_set_spectra(tamcmc_ctx *ctx, int32_t Nspectra, const double *y, const double *sigma_y);
+int tamcmc_ctx_set_chain_spectrum(tamcmc_ctx *ctx, int32_t Nchains, const int32_t *spectrum_of_chain);
+
 /* Replaces: the `for chain` loop of generate_model() calls (MALA.cpp:632-639, model_def.cpp:139-143).
  * Host pointers, row-major.  Synchronous: results are valid on return.
  *   params      Nchains x Nparams

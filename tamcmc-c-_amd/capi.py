@@ -17,7 +17,8 @@ OK, E_INVALID, E_NODEVICE, E_HIP, E_MODEL_DISABLED, E_UNKNOWN_MODEL, E_NOMEM, E_
 CHAIN_OK, CHAIN_NAN, CHAIN_EMPTY_WINDOW = 0, 1, 2
 
 EXPORTS = [
-    "tamcmc_ctx_create", "tamcmc_ctx_set_vars", "tamcmc_eval_batch", "tamcmc_eval_batch_device",
+    "tamcmc_ctx_create", "tamcmc_ctx_set_vars", "tamcmc_ctx_set_spectra", "tamcmc_ctx_set_chain_spectrum",
+    "tamcmc_eval_batch", "tamcmc_eval_batch_device",
     "tamcmc_eval_batch_begin", "tamcmc_eval_batch_end",
     "tamcmc_model_explicit", "tamcmc_ctx_set_stream", "tamcmc_ctx_synchronize", "tamcmc_ctx_profile",
     "tamcmc_ctx_kernel_time", "tamcmc_ctx_geometry", "tamcmc_ctx_destroy", "tamcmc_device_count",
@@ -138,6 +139,20 @@ class Accel:
         idx = np.ascontiguousarray(index_to_relax, dtype=np.int32)
         self._check(self._lib.tamcmc_ctx_set_vars(self._ctx, idx.size, _iptr(idx)), "tamcmc_ctx_set_vars")
         self.Nvars = int(idx.size)
+
+    def set_spectra(self, y, sigma_y=None):
+        """Several spectra on the context's grid (rows of y); chains choose theirs with set_chain_spectrum."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != self.Nx:
+            raise ValueError("y must be (Nspectra, Nx)")
+        sg = None if sigma_y is None else np.ascontiguousarray(sigma_y, dtype=np.float64)
+        if sg is not None and sg.shape != y.shape:
+            raise ValueError("sigma_y must have the shape of y")
+        self._check(self._lib.tamcmc_ctx_set_spectra(self._ctx, y.shape[0], _dptr(y), _dptr(sg)), "tamcmc_ctx_set_spectra")
+
+    def set_chain_spectrum(self, spectrum_of_chain):
+        m = np.ascontiguousarray(spectrum_of_chain, dtype=np.int32)
+        self._check(self._lib.tamcmc_ctx_set_chain_spectrum(self._ctx, m.size, _iptr(m)), "tamcmc_ctx_set_chain_spectrum")
 
     def eval_batch(self, params, Tcoefs, grad=False, model_rows=None):
         """Returns (logL, status[, grad][, models])."""

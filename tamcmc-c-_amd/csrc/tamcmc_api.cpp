@@ -43,6 +43,9 @@ struct tamcmc_ctx {
     hipStream_t stream = nullptr;
     // resident data
     double *d_x = nullptr, *d_y = nullptr, *d_lx = nullptr, *d_isig2 = nullptr;
+    int nspec = 1;                 // spectra resident in d_y / d_isig2 (blocks of Nx); tamcmc_ctx_set_spectra
+    int32_t *d_spec = nullptr;     // [spec_n] chain -> spectrum map (tamcmc_ctx_set_chain_spectrum), or NULL: all chains use spectrum 0
+    int spec_n = 0;
     // per-batch buffers (capacity in chains)
     int cap = 0;
     bool cap_grad = false;
@@ -301,7 +304,7 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_batch(c);
-    (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2);
+    (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2); (void)hipFree(c->d_spec);
     (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
     (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -323,6 +326,44 @@ extern "C" int tamcmc_ctx_set_vars(tamcmc_ctx *c, int32_t Nvars, const int32_t *
     if (Nvars > 0) {
         TM_HIP(hipMalloc(&c->d_relax, (size_t)Nvars * sizeof(int32_t)));
         TM_HIP(hipMemcpy(c->d_relax, index_to_relax, (size_t)Nvars * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_set_spectra(tamcmc_ctx *c, int32_t Nspectra, const double *y, const double *sigma_y)
+{
+    if (!c || Nspectra < 1 || !y || (c->L.likelihood_case == 1 && !sigma_y)) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    const size_t nx = (size_t)c->L.Nx, bytes = nx * (size_t)Nspectra * sizeof(double);
+    (void)hipFree(c->d_y); c->d_y = nullptr;
+    (void)hipFree(c->d_isig2); c->d_isig2 = nullptr;
+    (void)hipFree(c->d_spec); c->d_spec = nullptr; c->spec_n = 0;
+    c->nspec = 1;
+    if (hipMalloc(&c->d_y, bytes) != hipSuccess) return TAMCMC_E_NOMEM;
+    TM_HIP(hipMemcpy(c->d_y, y, bytes, hipMemcpyHostToDevice));
+    if (c->L.likelihood_case == 1) {
+        std::vector<double> tmp(nx * (size_t)Nspectra);
+        for (size_t i = 0; i < tmp.size(); i++) tmp[i] = 1.0 / (sigma_y[i] * sigma_y[i]);  // likelihoods.cpp:36
+        if (hipMalloc(&c->d_isig2, bytes) != hipSuccess) return TAMCMC_E_NOMEM;
+        TM_HIP(hipMemcpy(c->d_isig2, tmp.data(), bytes, hipMemcpyHostToDevice));
+    }
+    c->nspec = Nspectra;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_set_chain_spectrum(tamcmc_ctx *c, int32_t Nchains, const int32_t *spectrum_of_chain)
+{
+    if (!c || Nchains < 0 || (Nchains > 0 && !spectrum_of_chain)) return TAMCMC_E_INVALID;
+    for (int m = 0; m < Nchains; m++)
+        if (spectrum_of_chain[m] < 0 || spectrum_of_chain[m] >= c->nspec) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_spec); c->d_spec = nullptr; c->spec_n = 0;
+    if (Nchains > 0) {
+        TM_HIP(hipMalloc(&c->d_spec, (size_t)Nchains * sizeof(int32_t)));
+        TM_HIP(hipMemcpy(c->d_spec, spectrum_of_chain, (size_t)Nchains * sizeof(int32_t), hipMemcpyHostToDevice));
+        c->spec_n = Nchains;
     }
     return TAMCMC_OK;
 }
@@ -401,6 +442,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) c->last_tiles = tiles;
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
+    a.spec = (c->d_spec != nullptr && Nchains <= c->spec_n) ? c->d_spec : nullptr;
     a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.wt = c->d_wt;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
     a.row_of_chain = d_rows; a.model_out = d_model;

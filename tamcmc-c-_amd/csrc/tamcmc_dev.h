@@ -91,6 +91,7 @@ struct TmEvalArgs {
     const TmNoise *noise;
     const TmTileRec *trec;      // [Nchains][tiles]
     const int32_t *tidx;        // [Nchains][tiles][n_mult] active multiplet indices, table order
+    const int32_t *spec;        // NULL, or [Nchains]: which of the context's spectra (y, 1/sigma^2 blocks of Nx) a chain is fitted to
     const double *wt;            // [Nchains][2] {Tcoefs[chain], p/T or 2/T} copied by the setup kernel into device memory
     double *part;               // [Nchains][tiles][2]
     double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL

@@ -336,6 +336,12 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     // Everything a tile needs -- its list of active multiplets (table order), the background polynomial, the
     // chain's noise record, the multiplet records themselves -- was prepared by the setup kernel and is
     // wave-uniform: it is fetched with s_load into SGPRs.  No LDS staging, no barrier before the first bin.
+    // the chain's spectrum: contexts holding several spectra on one grid (ensembles, tamcmc_ctx_set_spectra) keep them as
+    // consecutive blocks of Nx
+    // (read through the constant address space: a scalar load, so that the two base pointers stay in SGPRs)
+    const size_t spec_off = (a.spec != nullptr) ? (size_t)((TmIdxK)a.spec)[chain] * (size_t)a.Nx : 0;
+    const double *__restrict__ yp = a.y + spec_off;
+    const double *__restrict__ isp = a.isig2 + spec_off;      // dereferenced only when the likelihood is chi_square (then non-NULL)
     const TmMult *__restrict__ gm = a.mult + (size_t)chain * a.n_mult;
     TmTileRecK tr = (TmTileRecK)(a.trec + (size_t)chain * a.tiles + tile);
     TmIdxK tix = (TmIdxK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
@@ -471,7 +477,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                     // Newton steps); a negative one is caught by the running minimum.  Either way logL becomes NaN,
                     // which is what log() of such a value gives the reference.
                     const double M = acc[k];
-                    const double yv = a.y[bi[k]];
+                    const double yv = yp[bi[k]];
                     Mmin = __builtin_fmin(Mmin, M);
                     const double rM = tm_rcp(M);
                     S1 = __builtin_fma(yv, rM, S1);
@@ -493,8 +499,8 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
             for (int k = 0; k < KU; k++) {
                 double wv = 0.0;
                 if (bi[k] >= 0) {
-                    const double dd = a.y[bi[k]] - acc[k];
-                    const double is2 = a.isig2[bi[k]];
+                    const double dd = yp[bi[k]] - acc[k];
+                    const double is2 = isp[bi[k]];
                     S1 = __builtin_fma(dd * dd, is2, S1);
                     wv = wscale * dd * is2;
                 }

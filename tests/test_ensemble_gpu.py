@@ -57,3 +57,54 @@ def test_concurrent_contexts_equal_sequential(accel_mod, orc):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_several_spectra_in_one_batch(accel_mod, orc):
+    """Ensemble on ONE context: several spectra on the same grid, each chain fitted to its own (tamcmc_ctx_set_spectra /
+    tamcmc_ctx_set_chain_spectrum).  Bit for bit what one context per spectrum returns, and within tolerance of the oracle."""
+    nspec, nch = 4, 5
+    w = synth.workload_c2(Nx=30000)
+    m, st = orc.model(2, w["params_true"], w["plength"], w["x"])
+    assert st == 0
+    Y = np.stack([synth.make_spectrum(m, seed=500 + k) for k in range(nspec)])
+    P = synth.chain_params(w, nspec * nch, seed=77)
+    T = np.tile(synth.temperatures(nch), nspec)
+    spec = np.repeat(np.arange(nspec, dtype=np.int32), nch)
+    perm = np.random.default_rng(5).permutation(nspec * nch)         # chains of one spectrum need not be adjacent
+    P, T, spec = P[perm], T[perm], spec[perm]
+    with accel_mod.Accel(2, w["plength"], w["x"], Y[0]) as acc:
+        acc.set_vars(w["index_to_relax"])
+        acc.set_spectra(Y)
+        acc.set_chain_spectrum(spec)
+        L, st, models = acc.eval_batch(P, T, model_rows=[0])
+        Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        with pytest.raises(accel_mod.AccelError):
+            acc.set_chain_spectrum(np.full(3, nspec, dtype=np.int32))     # out of range
+    for k in range(nspec):
+        sel = np.flatnonzero(spec == k)
+        with accel_mod.Accel(2, w["plength"], w["x"], Y[k]) as one:
+            one.set_vars(w["index_to_relax"])
+            L1, st1 = one.eval_batch(P[sel], T[sel])
+            Lg1, _, g1 = one.eval_batch(P[sel], T[sel], grad=True)
+        assert np.array_equal(L[sel], L1) and np.array_equal(st[sel], st1)
+        assert np.array_equal(Lg[sel], Lg1) and np.array_equal(g[sel], g1)
+        rL, rst = orc.generate_batch(2, w["plength"], w["x"], Y[k], P[sel], T[sel])
+        assert np.array_equal(st[sel], rst)
+        assert np.max(np.abs(L[sel] - rL) / np.abs(rL)) <= 1e-10
+    # chi-square likelihood with per-spectrum sigma, on the fused one-tile path as well (Nx = 900)
+    w = synth.workload_c1(Nx=900)
+    m, st = orc.model(w["model_case"], w["params_true"], w["plength"], w["x"])
+    Y = np.stack([synth.make_spectrum(m, seed=900 + k) for k in range(3)])
+    S = np.stack([0.05 + 0.1 * (k + 1) * np.abs(np.sin(np.arange(900))) for k in range(3)])
+    P = synth.chain_params(w, 6, seed=3)
+    T = synth.temperatures(6)
+    spec = np.array([2, 0, 1, 1, 0, 2], dtype=np.int32)
+    with accel_mod.Accel(w["model_case"], w["plength"], w["x"], Y[0], sigma_y=S[0], likelihood_case=1) as acc:
+        acc.set_spectra(Y, S)
+        acc.set_chain_spectrum(spec)
+        L, st = acc.eval_batch(P, T)
+    for k in range(3):
+        sel = np.flatnonzero(spec == k)
+        rL, rst = orc.generate_batch(w["model_case"], w["plength"], w["x"], Y[k], P[sel], T[sel], sigma_y=S[k], likelihood_case=1)
+        assert np.array_equal(st[sel], rst)
+        assert np.max(np.abs(L[sel] - rL) / np.abs(rL)) <= 1e-10

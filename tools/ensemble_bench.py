@@ -69,12 +69,32 @@ def rate_threads(ctxs, grad):
     return sum(b[0] for _, b in ctxs) * steps / dt
 
 
+def make_multi(nstars, nch):
+    """the same ensemble as ONE context holding all the spectra, every chain fitted to its own (tamcmc_ctx_set_spectra)"""
+    w = synth.workload_c2()
+    Y = np.stack([np.abs(np.sin(np.arange(w["x"].size) + 11 + k)) + 0.5 for k in range(nstars)])
+    acc = tamcmc_amd.Accel(2, w["plength"], w["x"], Y[0])
+    acc.set_vars(w["index_to_relax"])
+    acc.set_spectra(Y)
+    acc.set_chain_spectrum(np.repeat(np.arange(nstars, dtype=np.int32), nch))
+    n = nstars * nch
+    P = torch.from_numpy(np.concatenate([synth.chain_params(w, nch, seed=11 + k) for k in range(nstars)])).to(dev)
+    T = torch.from_numpy(np.tile(synth.temperatures(nch), nstars)).to(dev)
+    L = torch.empty(n, dtype=torch.float64, device=dev)
+    G = torch.empty(n, w["index_to_relax"].size, dtype=torch.float64, device=dev)
+    S = torch.empty(n, dtype=torch.int32, device=dev)
+    return acc, (n, P, T, L, G, S)
+
+
 ens = [make(nch, 11 + k) for k in range(nstars)]
+multi = [make_multi(nstars, nch)]
 one = [make(nch * nstars, 5)]
 single = [ens[0]]
 for grad in (True, False):
     r_e, r_1, r_s = rate(ens, grad), rate(one, grad), rate(single, grad)
     r_t = rate_threads(ens, grad)
+    r_m = rate(multi, grad)
     print(f"{'logL+grad' if grad else 'logL only'}: {nstars} stars x {nch} chains on {nstars} streams {r_e:,.0f} chain-steps/s "
           f"(one host thread per star: {r_t:,.0f}); "
-          f"one context x {nch * nstars} chains {r_1:,.0f}; one star x {nch} chains alone {r_s:,.0f}")
+          f"the same ensemble as one context with {nstars} spectra {r_m:,.0f}; "
+          f"one context x {nch * nstars} chains of one star {r_1:,.0f}; one star x {nch} chains alone {r_s:,.0f}")
