@@ -36,3 +36,35 @@ def test_hip_and_oracle_drive_identical_chains(accel_mod, orc):
         assert np.allclose(hip.get("logL"), ref.get("logL"), rtol=1e-10)
         assert mv_ref.mean() > 0.05 and (sw_ref >= 0).sum() > 100
         hip.close()
+
+
+@pytest.mark.parametrize("Nx,nch,nit", [(900, 5, 1500), (2048, 3, 800), (12000, 12, 300)])
+def test_hip_and_oracle_drive_identical_chains_local_model(accel_mod, orc, Nx, nch, nit):
+    """The same on a local model (id 11) for grids that take the fused one-launch path (<= 2048 bins, the size of the
+    reference's own example slices) and one that does not: thousands of begin / watch-the-results / end cycles.
+    The proposal is frozen here (Acquire phase).  While it adapts, the acceptance PROBABILITY feeds the step size
+    (MALA.cpp:560-572), so the 1e-16 relative differences between the two evaluators' logL enter the proposals and grow
+    chaotically: on this model the decisions of an adapting run part ways after ~250 iterations, with every single
+    evaluation still agreeing to 1e-15 (checked in lockstep).  With a frozen proposal a decision can differ only if a
+    uniform draw falls between two acceptance ratios that agree to 1e-13."""
+    import workloads as W
+    w = W.any_model(11, Nx=Nx, trunc_c=20.0)
+    m, _ = orc.model(11, w["params_true"], w["plength"], w["x"])
+    y = synth.make_spectrum(m, seed=33)
+    err = 0.002 * np.abs(w["params_true"][w["index_to_relax"]]) + 1e-6
+
+    def build(evaluator):
+        cfg = S.default_cfg(nch, seed=99, Nt_learn=(10 ** 9, 10 ** 9 + 1, 10 ** 9 + 2), periods_learn=(1, 2), prior_fct_switch=0, dN_mixing=3)
+        smp = S.Sampler(cfg, evaluator, w["plength"], w["params_true"], w["relax"], err)
+        smp.init()
+        return smp
+
+    ref = build(tps.oracle_evaluator(orc, 11, w, y))
+    mv_ref, sw_ref = ref.run(nit)
+    with accel_mod.Accel(11, w["plength"], w["x"], y) as acc:
+        hip = build(acc)
+        mv_hip, sw_hip = hip.run(nit)
+        assert np.array_equal(mv_hip, mv_ref) and np.array_equal(sw_hip, sw_ref)
+        assert np.allclose(hip.get("logL"), ref.get("logL"), rtol=1e-10)
+        assert 0.02 < mv_ref.mean() < 0.98
+        hip.close()
