@@ -43,7 +43,7 @@ def test_hip_and_oracle_drive_identical_chains_local_model(accel_mod, orc, Nx, n
     """The same on a local model (id 11) for grids that take the fused one-launch path (<= 2048 bins, the size of the
     reference's own example slices) and one that does not: thousands of begin / watch-the-results / end cycles.
     The proposal is frozen here (Acquire phase).  While it adapts, the acceptance PROBABILITY feeds the step size
-    (MALA.cpp:560-572), so the 1e-16 relative differences between the two evaluators' logL enter the proposals and grow
+    (MALA.cpp:312,534,651), so the 1e-16 relative differences between the two evaluators' logL enter the proposals and grow
     chaotically: on this model the decisions of an adapting run part ways after ~250 iterations, with every single
     evaluation still agreeing to 1e-15 (checked in lockstep).  With a frozen proposal a decision can differ only if a
     uniform draw falls between two acceptance ratios that agree to 1e-13."""
