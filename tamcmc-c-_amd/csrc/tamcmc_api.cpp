@@ -336,18 +336,19 @@ extern "C" int tamcmc_ctx_set_spectra(tamcmc_ctx *c, int32_t Nspectra, const dou
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
     const size_t nx = (size_t)c->L.Nx, bytes = nx * (size_t)Nspectra * sizeof(double);
-    (void)hipFree(c->d_y); c->d_y = nullptr;
-    (void)hipFree(c->d_isig2); c->d_isig2 = nullptr;
-    (void)hipFree(c->d_spec); c->d_spec = nullptr; c->spec_n = 0;
-    c->nspec = 1;
-    if (hipMalloc(&c->d_y, bytes) != hipSuccess) return TAMCMC_E_NOMEM;
-    TM_HIP(hipMemcpy(c->d_y, y, bytes, hipMemcpyHostToDevice));
+    // the new blocks first, the swap last: a failure leaves the context as it was
+    double *ny = nullptr, *nis = nullptr;
+    if (hipMalloc(&ny, bytes) != hipSuccess) return TAMCMC_E_NOMEM;
+    if (hipMemcpy(ny, y, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(ny); return TAMCMC_E_HIP; }
     if (c->L.likelihood_case == 1) {
         std::vector<double> tmp(nx * (size_t)Nspectra);
         for (size_t i = 0; i < tmp.size(); i++) tmp[i] = 1.0 / (sigma_y[i] * sigma_y[i]);  // likelihoods.cpp:36
-        if (hipMalloc(&c->d_isig2, bytes) != hipSuccess) return TAMCMC_E_NOMEM;
-        TM_HIP(hipMemcpy(c->d_isig2, tmp.data(), bytes, hipMemcpyHostToDevice));
+        if (hipMalloc(&nis, bytes) != hipSuccess) { (void)hipFree(ny); return TAMCMC_E_NOMEM; }
+        if (hipMemcpy(nis, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(ny); (void)hipFree(nis); return TAMCMC_E_HIP; }
     }
+    (void)hipFree(c->d_y); c->d_y = ny;
+    if (c->L.likelihood_case == 1) { (void)hipFree(c->d_isig2); c->d_isig2 = nis; }
+    (void)hipFree(c->d_spec); c->d_spec = nullptr; c->spec_n = 0;
     c->nspec = Nspectra;
     return TAMCMC_OK;
 }
