@@ -12,7 +12,8 @@ from tamcmc_amd import synth
 
 # usage: kstats.py [c2|c4|c1] [chains]
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
-w = {"c2": synth.workload_c2, "c4": synth.workload_c4, "c1": synth.workload_c1}[which]()
+kw = {"trunc_c": float(os.environ["TRUNC_C"])} if "TRUNC_C" in os.environ else {}     # TRUNC_C=10000: every window spans the grid
+w = {"c2": synth.workload_c2, "c4": synth.workload_c4, "c1": synth.workload_c1}[which](**kw)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 P = synth.chain_params(w, n); T = synth.temperatures(n)
 y = np.abs(np.sin(np.arange(w["x"].size))) + 0.5
