@@ -78,8 +78,9 @@ int tamcmc_ctx_set_vars(tamcmc_ctx *ctx, int32_t Nvars, const int32_t *index_to_
  * chains share a batch (one launch at the full-batch rate; separate contexts on separate streams overlap only ~1.5x,
  * DESIGN.md section 6).  set_spectra replaces the resident spectrum by Nspectra blocks of Nx (sigma_y likewise, NULL
  * unless the likelihood is chi_square) and clears the map; set_chain_spectrum says which spectrum chain m of the
- * following batches is fitted to (batches longer than the map, or no map, use spectrum 0 for every chain).  A chain's
- * result is bit for bit what a context holding only its spectrum returns. */
+ * following batches is fitted to.  While more than one spectrum is resident every batch must be covered by the map:
+ * an evaluation of more chains than the map holds (or without a map) returns TAMCMC_E_INVALID instead of fitting the
+ * uncovered chains to spectrum 0.  A chain's result is bit for bit what a context holding only its spectrum returns. */
 int tamcmc_ctx_set_spectra(tamcmc_ctx *ctx, int32_t Nspectra, const double *y, const double *sigma_y);
 int tamcmc_ctx_set_chain_spectrum(tamcmc_ctx *ctx, int32_t Nchains, const int32_t *spectrum_of_chain);
 
@@ -128,6 +129,13 @@ int tamcmc_ctx_synchronize(tamcmc_ctx *ctx);
  * duration and the number of launches since profiling was enabled. */
 int tamcmc_ctx_profile(tamcmc_ctx *ctx, int enable);
 int tamcmc_ctx_kernel_time(tamcmc_ctx *ctx, double *total_ms, int64_t *launches);
+
+/* Shader-clock probe: _begin launches ONE wave on a stream of its own that watches the core-cycle counter against the
+ * constant 100 MHz counter for `milliseconds`; _end waits for it and returns the mean core clock over that window.
+ * Evaluations enqueued between the two calls run beside it, so this is the clock under that load (used by bench.py to
+ * turn instruction counts into a fraction of the fp64 issue rate with a clock measured in the same run). */
+int tamcmc_ctx_clock_probe_begin(tamcmc_ctx *ctx, double milliseconds);
+int tamcmc_ctx_clock_probe_end(tamcmc_ctx *ctx, double *core_GHz, double *seconds);
 
 /* Launch geometry actually used (for DESIGN.md / bench bookkeeping). */
 int tamcmc_ctx_geometry(tamcmc_ctx *ctx, int32_t *bins_per_tile, int32_t *tiles, int32_t *threads_per_block,

@@ -98,6 +98,36 @@ int tamcmc_sampler_end_iteration(tamcmc_sampler *s);
  * -1 no attempt, else 2*A + swapped. */
 int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, int32_t *swap_hist);
 
+/* Sharded runs, the whole loop in the library (MALA.cpp:608-737 for this process's block of chains): n_iter iterations
+ * of mh_step + parallel tempering + end_iteration.  A pair (A, A+1) owned here is swapped locally; when this process
+ * owns exactly one end, `exchange` is called with this end's exported record (n_doubles = tamcmc_sampler_pt_record_size)
+ * and must return the peer's record in recv -- the caller implements it as a neighbour send/recv (torch.distributed:
+ * RCCL on GPUs, gloo in the CPU tests; tamcmc-c-_amd/sharded.py); it returns 0 or non-zero on failure.  Processes that
+ * own neither end do not communicate.  moved_hist / swap_hist as in tamcmc_sampler_run, except that an attempt this
+ * process took no part in is recorded as -2.  With a block (below) the loop stops early when the block is full; *done
+ * (may be NULL) receives the number of iterations performed. */
+typedef int (*tamcmc_exchange_fn)(void *user, int32_t my_chain, int32_t peer_chain, const double *send, double *recv,
+                                  int32_t n_doubles);
+typedef struct tamcmc_shard_block tamcmc_shard_block;
+int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tamcmc_exchange_fn exchange, void *user,
+                               tamcmc_shard_block *block, uint8_t *moved_hist, int32_t *swap_hist, int64_t *done);
+/* A process's share of an output block (Outputs::update_buffer_*, outputs.cpp:863-1027): the samples of its chains and
+ * the running sums of the proposal parameters, filled by tamcmc_sampler_run_sharded, gathered by the caller once per
+ * block (rank 0 then writes the files through tamcmc_outputs_push_block).  data(which): 0 vars [n][nloc][Nvars],
+ * 1 stat [n][3][nloc] = logL | logPrior | logPost, 2 moved [n][nloc], 3 pt [n][4] = attempted, chain A, Pswitch (NaN
+ * unless an owner), switched (-1 unless an owner); sums over the block: 4 sigma, 5 mu, 6 covarmat, 7 vars. */
+int tamcmc_shard_block_create(tamcmc_shard_block **out, const tamcmc_sampler *s, int64_t capacity);
+int tamcmc_shard_block_data(tamcmc_shard_block *b, int32_t which, double **ptr, int64_t *count);
+int64_t tamcmc_shard_block_count(const tamcmc_shard_block *b);
+int tamcmc_shard_block_reset(tamcmc_shard_block *b);
+int tamcmc_shard_block_destroy(tamcmc_shard_block *b);
+
+/* Wall time spent per phase of the loop since set_timing(s, 1): seconds[0..7] = proposals, launch, priors, draws of the
+ * next iteration (overlapped with the GPU), wait, accept, raw draws of the chains owned by OTHER processes (the
+ * replicated-stream term of a sharded run, included in [3] or [0]), boundary exchange. */
+int tamcmc_sampler_set_timing(tamcmc_sampler *s, int32_t enable);
+int tamcmc_sampler_get_timing(const tamcmc_sampler *s, double seconds[8], int64_t *iterations);
+
 /* State access (local chains, row-major). which: 0 vars, 1 params, 2 logLikelihood (tempered), 3 logPrior,
  * 4 logPosterior, 5 Pmove, 6 sigma, 7 mu, 8 covarmat (n_local x Nvars x Nvars), 9 Tcoefs (local), 10 moved (0/1) */
 int tamcmc_sampler_get(const tamcmc_sampler *s, int32_t which, double *out, int64_t capacity);

@@ -21,7 +21,7 @@ EXPORTS = [
     "tamcmc_eval_batch", "tamcmc_eval_batch_device",
     "tamcmc_eval_batch_begin", "tamcmc_eval_batch_end",
     "tamcmc_model_explicit", "tamcmc_ctx_set_stream", "tamcmc_ctx_synchronize", "tamcmc_ctx_profile",
-    "tamcmc_ctx_kernel_time", "tamcmc_ctx_geometry", "tamcmc_ctx_destroy", "tamcmc_device_count",
+    "tamcmc_ctx_kernel_time", "tamcmc_ctx_clock_probe_begin", "tamcmc_ctx_clock_probe_end", "tamcmc_ctx_geometry", "tamcmc_ctx_destroy", "tamcmc_device_count",
     "tamcmc_strerror", "tamcmc_last_hip_error", "tamcmc_version",
 ]
 
@@ -58,6 +58,8 @@ def load_library():
     lib.tamcmc_ctx_synchronize.argtypes = [vp]
     lib.tamcmc_ctx_profile.argtypes = [vp, C.c_int]
     lib.tamcmc_ctx_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    lib.tamcmc_ctx_clock_probe_begin.argtypes = [vp, C.c_double]
+    lib.tamcmc_ctx_clock_probe_end.argtypes = [vp, dp, dp]
     lib.tamcmc_ctx_geometry.argtypes = [vp, ip, ip, ip, ip]
     lib.tamcmc_ctx_destroy.argtypes = [vp]
     lib.tamcmc_device_count.argtypes = []
@@ -207,6 +209,15 @@ class Accel:
         n = C.c_int64(0)
         self._check(self._lib.tamcmc_ctx_kernel_time(self._ctx, C.byref(ms), C.byref(n)), "tamcmc_ctx_kernel_time")
         return ms.value, n.value
+
+    def clock_probe_begin(self, milliseconds):
+        self._check(self._lib.tamcmc_ctx_clock_probe_begin(self._ctx, float(milliseconds)), "tamcmc_ctx_clock_probe_begin")
+
+    def clock_probe_end(self):
+        """(core clock in GHz, seconds observed) of the probe started by clock_probe_begin."""
+        ghz, sec = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._lib.tamcmc_ctx_clock_probe_end(self._ctx, C.byref(ghz), C.byref(sec)), "tamcmc_ctx_clock_probe_end")
+        return ghz.value, sec.value
 
     def geometry(self):
         v = [C.c_int32(0) for _ in range(4)]

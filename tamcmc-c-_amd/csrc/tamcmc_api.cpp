@@ -75,6 +75,9 @@ struct tamcmc_ctx {
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
+    // shader-clock probe (tamcmc_ctx_clock_probe_begin / _end): one wave on its own stream beside the evaluation
+    hipStream_t probe_stream = nullptr;
+    unsigned long long *h_probe = nullptr, *dv_probe = nullptr;   // pinned: {core cycles, 100 MHz ticks}
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
@@ -307,6 +310,8 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2); (void)hipFree(c->d_spec);
     (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
     (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
+    if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
+    (void)hipHostFree(c->h_probe);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -412,6 +417,46 @@ extern "C" int tamcmc_ctx_kernel_time(tamcmc_ctx *c, double *total_ms, int64_t *
     return TAMCMC_OK;
 }
 
+// One wave that does nothing but watch two counters for `ticks` ticks of the constant 100 MHz clock: s_memtime counts
+// shader-core cycles, s_memrealtime the constant clock, so their ratio is the core clock the GPU ran at meanwhile --
+// launched on a stream of its own beside the evaluation, it reads the clock UNDER THAT LOAD (bench.py: roofline.valu).
+__global__ void tamcmc_clock_probe_kernel(unsigned long long ticks, unsigned long long *out)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    unsigned long long r1 = r0, c1 = c0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(32); r1 = wall_clock64(); c1 = clock64(); }
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
+extern "C" int tamcmc_ctx_clock_probe_begin(tamcmc_ctx *c, double milliseconds)
+{
+    if (!c || !(milliseconds > 0.0) || milliseconds > 2000.0) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    if (!c->probe_stream) TM_HIP(hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+    if (!c->h_probe) {
+        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_probe), 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dv_probe), c->h_probe, 0));
+    }
+    c->h_probe[0] = c->h_probe[1] = 0;
+    hipLaunchKernelGGL(tamcmc_clock_probe_kernel, dim3(1), dim3(64), 0, c->probe_stream,
+                       (unsigned long long)(milliseconds * 1e5), c->dv_probe);
+    TM_HIP(hipGetLastError());
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_clock_probe_end(tamcmc_ctx *c, double *core_GHz, double *seconds)
+{
+    if (!c || !c->probe_stream || !core_GHz) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    TM_HIP(hipStreamSynchronize(c->probe_stream));
+    const double cyc = (double)c->h_probe[0], t = (double)c->h_probe[1] / 1e8;
+    *core_GHz = (t > 0.0) ? cyc / t / 1e9 : 0.0;
+    if (seconds) *seconds = t;
+    return TAMCMC_OK;
+}
+
 extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_t *tiles, int32_t *threads_per_block,
                                    int32_t *n_multiplets)
 {
@@ -436,6 +481,9 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
                    double *d_grad, int32_t *d_status, const int32_t *d_rows, double *d_model)
 {
     const bool grad = d_grad != nullptr;
+    // several spectra resident: every chain of the batch must have been told which one it is fitted to (a batch longer
+    // than the map used to fall back to spectrum 0 for all chains -- silently the wrong data)
+    if (c->nspec > 1 && (c->d_spec == nullptr || Nchains > c->spec_n)) return TAMCMC_E_INVALID;
     const int K = grad ? c->Kg : c->K;
     const int units = grad ? c->units_g : c->units;
     const int tiles = pick_tiles(c, Nchains, grad);
@@ -443,7 +491,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) c->last_tiles = tiles;
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
-    a.spec = (c->d_spec != nullptr && Nchains <= c->spec_n) ? c->d_spec : nullptr;
+    a.spec = (c->nspec > 1) ? c->d_spec : nullptr;
     a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.wt = c->d_wt;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
     a.row_of_chain = d_rows; a.model_out = d_model;
@@ -480,7 +528,11 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     } else {
         rc = tm_launch_eval(a, Nchains, K, grad, c->stream);
     }
-    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "eval launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    if (rc != 0) {
+        snprintf(g_hip_err, sizeof(g_hip_err), "eval launch -> %s", hipGetErrorString((hipError_t)rc));
+        (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);   // arrival counters back to zero
+        return TAMCMC_E_HIP;
+    }
     if (c->profile) {
         TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
@@ -554,8 +606,24 @@ static int wait_data(tamcmc_ctx *c, int n, size_t nw)
         __builtin_ia32_pause();
         if ((++spins & 2047u) == 0) {
             const hipError_t e = hipEventQuery(c->ev_done);
-            if (e == hipSuccess) return TAMCMC_OK;       // the launch has retired: whatever the slots hold is final
-            if (e != hipErrorNotReady) { snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e)); return TAMCMC_E_HIP; }
+            if (e == hipSuccess) {
+                // The launch has retired: whatever the slots hold is final.  A logL / status slot that still holds its
+                // marker was never written -- a chain whose finalize did not run (e.g. an arrival counter left non-zero
+                // by an earlier failed launch).  Report it instead of handing the marker out as a result, and re-arm
+                // the counters so that the context is usable again.
+                for (size_t k = 0; k < (size_t)n; k++)
+                    if (o[k] == TM_PENDING_BITS || st[k] == -1) {
+                        snprintf(g_hip_err, sizeof(g_hip_err), "chain %zu was not finalized by a retired launch", k);
+                        (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);
+                        return TAMCMC_E_HIP;
+                    }
+                return TAMCMC_OK;
+            }
+            if (e != hipErrorNotReady) {
+                snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e));
+                (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);
+                return TAMCMC_E_HIP;
+            }
         }
     }
     return TAMCMC_OK;

@@ -6,11 +6,18 @@
 // tamcmc_setup_kernel) and then tm_eval_body for the chain's only tile (tamcmc_eval_body.h: same code as
 // tamcmc_eval_kernel), so the results are those of the two-launch path bit for bit.
 //
-// The eval body reads the records through the constant address space (scalar loads).  Here the same launch has just
-// written them, so (i) the stores are made visible first (__threadfence: vector stores reach L2, which the scalar cache
-// misses into; nothing can be stale in the scalar cache, these addresses have not been read in this launch), and (ii)
-// the pointers handed to the eval body are passed through an opaque asm, so that the compiler cannot schedule a
-// constant-address-space load -- which it may otherwise move anywhere -- ahead of the barrier.
+// The eval body reads the records through the constant address space (scalar loads through the scalar data cache,
+// which is NOT coherent with vector stores and is shared by neighbouring CUs).  Here the same launch has just written
+// them, so
+//  (i)   the stores are made visible first (__threadfence: the vector stores reach L2, which the scalar cache misses
+//        into);
+//  (ii)  the scalar cache is invalidated (s_dcache_inv) before the first record is read.  The per-chain records are not
+//        multiples of a cache line (TmNoise 120 B, TmMult 160 B x n_mult, the active list 4 B x n_mult, wt 16 B), so the
+//        records of chains c and c+1 share lines: a workgroup that scalar-loads such a line BEFORE its neighbour's
+//        stores have landed leaves a stale copy behind, which the neighbour -- if it shares the scalar cache -- would
+//        then hit.  (In SPX mode consecutive workgroups go to different XCDs, which hides this; nothing guarantees it.)
+//  (iii) the pointers handed to the eval body are passed through an opaque asm, so that the compiler cannot schedule a
+//        constant-address-space load -- which it may otherwise move anywhere -- ahead of the barrier.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
 #include "tamcmc_setup_body.h"
@@ -27,6 +34,7 @@ __global__ __launch_bounds__(TM_THREADS) void tamcmc_fused_kernel(TmLayout L, Tm
                               static_cast<TmMultFull *>(f.aux), f.hser, nullptr, s_dyn);
     __threadfence();
     __syncthreads();
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     TmEvalArgs b = a;
     asm volatile("" : "+s"(b.mult), "+s"(b.noise), "+s"(b.trec), "+s"(b.tidx), "+s"(b.wt) : : "memory");
     tm_eval_body<KU, GRAD>(b, chain, 0, s_dyn + f.p_doubles);

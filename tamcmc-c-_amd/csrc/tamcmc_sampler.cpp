@@ -470,7 +470,7 @@ struct tamcmc_sampler {
     std::vector<double> p_prop, v_prop, L_prop, lpr_prop, u_mh, u_now, z, z_all, chol_scratch;
     std::vector<int> perr_prop;
     bool timing = false;             // developer switch TAMCMC_SAMPLER_TIMING=1: phase times of mh_step, printed at destroy
-    double t_phase[6] = {0, 0, 0, 0, 0, 0};   // proposals, launch, priors, draw-ahead, wait, accept (seconds)
+    double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // proposals, launch, priors, draw-ahead, wait, accept, raw draws of chains owned elsewhere, exchange (seconds)
     int64_t t_iters = 0;
     std::vector<int32_t> status;
     std::vector<Rng::NormalPlan> plans;          // one per local chain (+1 for chains owned elsewhere)
@@ -656,16 +656,25 @@ static bool learning_now(const tamcmc_sampler *s, int64_t i, int64_t *period)
 }
 
 // MH draws of one iteration in the reference's order: for each chain, u then z (MALA.cpp:451,465,346)
+static inline double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Every process consumes the WHOLE stream (that is what makes a sharded run the single-process run, bit for bit), so
+// the draws of the chains owned elsewhere are a serial term that grows with the global chain count while the GPU work
+// per process shrinks; t_phase[6] keeps its share (tamcmc_sampler_get_timing) so that a sharded bench can report it.
 static void draw_mh(tamcmc_sampler *s)
 {
-    const int n = s->nloc, nv = s->Nvars, off = s->cfg.chain_offset;
-    for (int g = 0; g < s->cfg.Nchains; g++) {
-        const double u = s->rng.uniform();
-        const int m = g - off;
-        const bool mine = (m >= 0 && m < n);
-        s->rng.draw(nv, s->plans[mine ? (size_t)m : (size_t)n]);
-        if (mine) s->u_mh[m] = u;
+    const int n = s->nloc, nv = s->Nvars, off = s->cfg.chain_offset, N = s->cfg.Nchains;
+    const bool tm = s->timing && n < N;
+    double t0 = tm ? wall_now() : 0.0;
+    for (int g = 0; g < off; g++) { (void)s->rng.uniform(); s->rng.draw(nv, s->plans[(size_t)n]); }
+    if (tm) { const double t1 = wall_now(); s->t_phase[6] += t1 - t0; }
+    for (int m = 0; m < n; m++) {
+        s->u_mh[m] = s->rng.uniform();
+        s->rng.draw(nv, s->plans[(size_t)m]);
     }
+    if (tm) t0 = wall_now();
+    for (int g = off + n; g < N; g++) { (void)s->rng.uniform(); s->rng.draw(nv, s->plans[(size_t)n]); }
+    if (tm) { const double t1 = wall_now(); s->t_phase[6] += t1 - t0; }
 }
 
 static void draw_pt(tamcmc_sampler *s)
@@ -889,6 +898,139 @@ extern "C" int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *mo
     return TAMCMC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sharded runs: the iteration loop of MALA::execute (MALA.cpp:608-737) for the block of chains this process owns.
+// ------------------------------------------------------------------------------------------------
+struct tamcmc_shard_block {
+    int64_t cap = 0, n = 0;
+    int nloc = 0, nv = 0;
+    std::vector<double> vars, stat, moved, pt;         // [cap][nloc][nv], [cap][3][nloc], [cap][nloc], [cap][4]
+    std::vector<double> sum_sigma, sum_mu, sum_covar, sum_vars;
+};
+
+extern "C" int tamcmc_shard_block_create(tamcmc_shard_block **out, const tamcmc_sampler *s, int64_t capacity)
+{
+    if (!out || !s || capacity < 1) return TAMCMC_E_INVALID;
+    tamcmc_shard_block *b = new (std::nothrow) tamcmc_shard_block();
+    if (!b) return TAMCMC_E_NOMEM;
+    b->cap = capacity; b->nloc = s->nloc; b->nv = s->Nvars;
+    const size_t n = (size_t)s->nloc, nv = (size_t)s->Nvars, c = (size_t)capacity;
+    b->vars.resize(c * n * nv); b->stat.resize(c * 3 * n); b->moved.resize(c * n); b->pt.resize(c * 4);
+    b->sum_sigma.assign(n, 0.0); b->sum_mu.assign(n * nv, 0.0); b->sum_covar.assign(n * nv * nv, 0.0); b->sum_vars.assign(n * nv, 0.0);
+    *out = b;
+    return TAMCMC_OK;
+}
+extern "C" int tamcmc_shard_block_destroy(tamcmc_shard_block *b) { delete b; return TAMCMC_OK; }
+extern "C" int64_t tamcmc_shard_block_count(const tamcmc_shard_block *b) { return b ? b->n : -1; }
+extern "C" int tamcmc_shard_block_reset(tamcmc_shard_block *b)
+{
+    if (!b) return TAMCMC_E_INVALID;
+    b->n = 0;
+    std::fill(b->sum_sigma.begin(), b->sum_sigma.end(), 0.0); std::fill(b->sum_mu.begin(), b->sum_mu.end(), 0.0);
+    std::fill(b->sum_covar.begin(), b->sum_covar.end(), 0.0); std::fill(b->sum_vars.begin(), b->sum_vars.end(), 0.0);
+    return TAMCMC_OK;
+}
+extern "C" int tamcmc_shard_block_data(tamcmc_shard_block *b, int32_t which, double **ptr, int64_t *count)
+{
+    if (!b || !ptr || !count) return TAMCMC_E_INVALID;
+    std::vector<double> *v = nullptr;
+    size_t used = 0;
+    const size_t n = (size_t)b->nloc, nv = (size_t)b->nv, k = (size_t)b->n;
+    switch (which) {
+    case 0: v = &b->vars; used = k * n * nv; break;
+    case 1: v = &b->stat; used = k * 3 * n; break;
+    case 2: v = &b->moved; used = k * n; break;
+    case 3: v = &b->pt; used = k * 4; break;
+    case 4: v = &b->sum_sigma; used = v->size(); break;
+    case 5: v = &b->sum_mu; used = v->size(); break;
+    case 6: v = &b->sum_covar; used = v->size(); break;
+    case 7: v = &b->sum_vars; used = v->size(); break;
+    default: return TAMCMC_E_INVALID;
+    }
+    *ptr = v->data(); *count = (int64_t)used;
+    return TAMCMC_OK;
+}
+
+// one sample of the local chains (what Outputs::update_buffer_* keep, outputs.cpp:863-1027) and the running sums of
+// the proposal parameters (the *_mean entries of the restore files)
+static void shard_block_record(tamcmc_shard_block *b, const tamcmc_sampler *s, double att, double A, double r, double sw)
+{
+    const size_t n = (size_t)b->nloc, nv = (size_t)b->nv, k = (size_t)b->n;
+    std::memcpy(&b->vars[k * n * nv], s->vars.data(), sizeof(double) * n * nv);
+    std::memcpy(&b->stat[(k * 3 + 0) * n], s->logL.data(), sizeof(double) * n);
+    std::memcpy(&b->stat[(k * 3 + 1) * n], s->logPrior.data(), sizeof(double) * n);
+    std::memcpy(&b->stat[(k * 3 + 2) * n], s->logPost.data(), sizeof(double) * n);
+    for (size_t m = 0; m < n; m++) b->moved[k * n + m] = (double)s->moved[m];
+    b->pt[k * 4 + 0] = att; b->pt[k * 4 + 1] = A; b->pt[k * 4 + 2] = r; b->pt[k * 4 + 3] = sw;
+    for (size_t e = 0; e < n; e++) b->sum_sigma[e] += s->sigma[e];
+    for (size_t e = 0; e < n * nv; e++) { b->sum_mu[e] += s->mu[e]; b->sum_vars[e] += s->vars[e]; }
+    for (size_t e = 0; e < n * nv * nv; e++) b->sum_covar[e] += s->covar[e];
+    b->n++;
+}
+
+extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tamcmc_exchange_fn exchange, void *user,
+                                          tamcmc_shard_block *block, uint8_t *moved_hist, int32_t *swap_hist, int64_t *done)
+{
+    if (!s || n_iter < 0) return TAMCMC_E_INVALID;
+    if (block && (block->nloc != s->nloc || block->nv != s->Nvars)) return TAMCMC_E_INVALID;
+    const int off = s->cfg.chain_offset, nloc = s->nloc, nrec = tamcmc_sampler_pt_record_size(s);
+    std::vector<double> send((size_t)nrec), recv((size_t)nrec);
+    int64_t k = 0;
+    if (done) *done = 0;
+    for (; k < n_iter; k++) {
+        if (block && block->n >= block->cap) break;                    // the caller gathers the block, resets it, calls again
+        int rc = tamcmc_sampler_mh_step(s);
+        if (rc != TAMCMC_OK) return rc;
+        if (moved_hist) std::memcpy(moved_hist + (size_t)k * nloc, s->moved.data(), (size_t)nloc);
+        double att = 0.0, Ad = -1.0, r = std::numeric_limits<double>::quiet_NaN(), swd = -1.0;
+        int32_t sh = -1;
+        if (tamcmc_sampler_pt_due(s)) {
+            int32_t A, swapped = 0; double u, rT = 0.0;
+            tamcmc_sampler_pt_draw(s, &A, &u);                        // same values in every process (replicated stream)
+            att = 1.0; Ad = (double)A; sh = -2;                       // -2: attempted, this process owns neither end
+            const bool ownA = (A >= off && A < off + nloc), ownB = (A + 1 >= off && A + 1 < off + nloc);
+            if (ownA && ownB) {
+                rc = tamcmc_sampler_pt_local(s, A, u, &swapped, &rT);
+                if (rc != TAMCMC_OK) return rc;
+                r = rT; swd = (double)swapped; sh = 2 * A + swapped;
+            } else if (ownA || ownB) {
+                if (!exchange) return TAMCMC_E_INVALID;
+                const int mine = ownA ? A : A + 1, peer = ownA ? A + 1 : A;
+                tamcmc_sampler_pt_export(s, mine, send.data());
+                const double t0 = s->timing ? wall_now() : 0.0;
+                rc = exchange(user, mine, peer, send.data(), recv.data(), nrec);
+                if (s->timing) s->t_phase[7] += wall_now() - t0;
+                if (rc != 0) return TAMCMC_E_INVALID;
+                rc = tamcmc_sampler_pt_import(s, A, u, recv.data(), &swapped, &rT);
+                if (rc != TAMCMC_OK) return rc;
+                r = rT; swd = (double)swapped; sh = 2 * A + swapped;
+            }
+        }
+        if (swap_hist) swap_hist[k] = sh;
+        if (block) shard_block_record(block, s, att, Ad, r, swd);
+        s->iter++;
+    }
+    if (done) *done = k;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_set_timing(tamcmc_sampler *s, int32_t enable)
+{
+    if (!s) return TAMCMC_E_INVALID;
+    s->timing = enable != 0;
+    for (double &t : s->t_phase) t = 0.0;
+    s->t_iters = 0;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_sampler_get_timing(const tamcmc_sampler *s, double seconds[8], int64_t *iterations)
+{
+    if (!s || !seconds) return TAMCMC_E_INVALID;
+    for (int i = 0; i < 8; i++) seconds[i] = s->t_phase[i];
+    if (iterations) *iterations = s->t_iters;
+    return TAMCMC_OK;
+}
+
 extern "C" int tamcmc_sampler_get(const tamcmc_sampler *s, int32_t which, double *out, int64_t cap)
 {
     if (!s || !out) return TAMCMC_E_INVALID;
@@ -929,6 +1071,7 @@ extern "C" int tamcmc_sampler_set(tamcmc_sampler *s, int32_t which, const double
     case 6:
         if ((size_t)count != n) return TAMCMC_E_INVALID;
         std::memcpy(s->sigma.data(), in, sizeof(double) * n);
+        std::fill(s->chol_valid.begin(), s->chol_valid.end(), 0);   // Lchol factors (covar + eps2 I) * sigma
         return TAMCMC_OK;
     case 7:
         if ((size_t)count != n * nv) return TAMCMC_E_INVALID;

@@ -12,6 +12,7 @@ from . import capi
 MAX_LEARN = 8
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                       C.POINTER(C.c_double), C.POINTER(C.c_int32))
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32)
 
 
 class SamplerCfg(C.Structure):
@@ -42,6 +43,15 @@ def _lib():
         lib.tamcmc_sampler_pt_export.argtypes = [vp, C.c_int32, dp]
         lib.tamcmc_sampler_pt_import.argtypes = [vp, C.c_int32, C.c_double, dp, ip, dp]
         lib.tamcmc_sampler_run.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint8), ip]
+        lib.tamcmc_sampler_run_sharded.argtypes = [vp, C.c_int64, EXCHANGE_FN, vp, vp, C.POINTER(C.c_uint8), ip, C.POINTER(C.c_int64)]
+        lib.tamcmc_shard_block_create.argtypes = [C.POINTER(vp), vp, C.c_int64]
+        lib.tamcmc_shard_block_data.argtypes = [vp, C.c_int32, C.POINTER(dp), C.POINTER(C.c_int64)]
+        lib.tamcmc_shard_block_count.argtypes = [vp]
+        lib.tamcmc_shard_block_count.restype = C.c_int64
+        lib.tamcmc_shard_block_reset.argtypes = [vp]
+        lib.tamcmc_shard_block_destroy.argtypes = [vp]
+        lib.tamcmc_sampler_set_timing.argtypes = [vp, C.c_int32]
+        lib.tamcmc_sampler_get_timing.argtypes = [vp, dp, C.POINTER(C.c_int64)]
         lib.tamcmc_sampler_get.argtypes = [vp, C.c_int32, dp, C.c_int64]
         lib.tamcmc_sampler_iteration.argtypes = [vp]
         lib.tamcmc_sampler_iteration.restype = C.c_int64
@@ -215,6 +225,41 @@ class Sampler:
         self._check(self._lib.tamcmc_sampler_get(self._h, which, _dp(out), out.size), "tamcmc_sampler_get")
         return out
 
+    def set_timing(self, enable=True):
+        self._check(self._lib.tamcmc_sampler_set_timing(self._h, 1 if enable else 0), "tamcmc_sampler_set_timing")
+
+    def timing(self):
+        """Seconds per phase since set_timing(True) and the iterations they cover (include/tamcmc_sampler.h)."""
+        sec, it = np.zeros(8), C.c_int64(0)
+        self._check(self._lib.tamcmc_sampler_get_timing(self._h, _dp(sec), C.byref(it)), "tamcmc_sampler_get_timing")
+        names = ("proposals", "launch", "priors", "draw_ahead", "wait", "accept", "foreign_draws", "exchange")
+        return dict(zip(names, sec.tolist())), int(it.value)
+
+    def run_sharded(self, n_iter, exchange=None, block=None, history=False):
+        """n_iter iterations of the sharded loop inside the library (tamcmc_sampler_run_sharded).  exchange(my_chain,
+        peer_chain, send: ndarray) -> ndarray is called only for a boundary pair with one end owned here."""
+        moved = np.zeros((n_iter, self.nloc), dtype=np.uint8) if history else None
+        swaps = np.zeros(n_iter, dtype=np.int32) if history else None
+        err = []
+
+        def cb(user, mine, peer, p_send, p_recv, n):
+            try:
+                out = exchange(int(mine), int(peer), np.ctypeslib.as_array(p_send, shape=(n,)))
+                np.ctypeslib.as_array(p_recv, shape=(n,))[:] = out
+                return 0
+            except BaseException as e:      # noqa: BLE001 -- must not propagate through the C frame
+                err.append(e)
+                return 1
+        fn = EXCHANGE_FN(cb) if exchange is not None else C.cast(None, EXCHANGE_FN)
+        done = C.c_int64(0)
+        rc = self._lib.tamcmc_sampler_run_sharded(self._h, n_iter, fn, None, block._h if block is not None else None,
+                                                  moved.ctypes.data_as(C.POINTER(C.c_uint8)) if history else None,
+                                                  _ip(swaps) if history else None, C.byref(done))
+        if err:
+            raise err[0]
+        self._check(rc, "tamcmc_sampler_run_sharded")
+        return int(done.value), moved, swaps
+
     def close(self):
         if self._h and self._h.value:
             self._lib.tamcmc_sampler_destroy(self._h)
@@ -227,28 +272,67 @@ class Sampler:
             pass
 
 
-def run_sharded(sampler, n_iter, dist, rank, world, chains_per_rank, device=None):
-    """n_iter iterations of a sharded run: MH step on the local chains, then the parallel-tempering attempt;
-    a boundary pair costs one neighbour send/recv each way (RCCL on the GPU box, gloo in the CPU tests)."""
+class ShardBlock:
+    """This process's share of an output block, filled by Sampler.run_sharded (tamcmc_shard_block_*)."""
+    NAMES = {"vars": 0, "stat": 1, "moved": 2, "pt": 3, "sum_sigma": 4, "sum_mu": 5, "sum_covar": 6, "sum_vars": 7}
+
+    def __init__(self, sampler, capacity):
+        self._lib = sampler._lib
+        self._h = C.c_void_p()
+        sampler._check(self._lib.tamcmc_shard_block_create(C.byref(self._h), sampler._h, int(capacity)), "tamcmc_shard_block_create")
+        self.nloc, self.nv = sampler.nloc, sampler.Nvars
+
+    def count(self):
+        return int(self._lib.tamcmc_shard_block_count(self._h))
+
+    def data(self, what):
+        """A copy of one array of the block, shaped (include/tamcmc_sampler.h)."""
+        ptr, cnt = C.POINTER(C.c_double)(), C.c_int64(0)
+        rc = self._lib.tamcmc_shard_block_data(self._h, self.NAMES[what], C.byref(ptr), C.byref(cnt))
+        if rc != 0:
+            raise capi.AccelError(rc, "tamcmc_shard_block_data", "invalid block array")
+        n, nl, nv = self.count(), self.nloc, self.nv
+        shape = {"vars": (n, nl, nv), "stat": (n, 3, nl), "moved": (n, nl), "pt": (n, 4), "sum_sigma": (nl,), "sum_mu": (nl, nv),
+                 "sum_covar": (nl, nv, nv), "sum_vars": (nl, nv)}[what]
+        if cnt.value == 0:
+            return np.empty(shape)
+        return np.ctypeslib.as_array(ptr, shape=(int(cnt.value),)).reshape(shape).copy()
+
+    def reset(self):
+        self._lib.tamcmc_shard_block_reset(self._h)
+
+    def close(self):
+        if self._h and self._h.value:
+            self._lib.tamcmc_shard_block_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def neighbour_exchange(dist, chains_per_rank, device=None):
+    """The boundary-pair exchange of a sharded run: one record each way between the two owners (torch.distributed
+    send/recv: RCCL over xGMI on GPUs -- tensors on `device` -- or gloo on the CPU)."""
     import torch
-    swaps = []
-    for _ in range(n_iter):
-        sampler.mh_step()
-        if sampler.pt_due():
-            A, u = sampler.pt_draw()                      # same values on every rank (replicated RNG stream)
-            rA, rB = A // chains_per_rank, (A + 1) // chains_per_rank
-            if rA == rB:
-                if rank == rA:
-                    swaps.append((A, sampler.pt_local(A, u)[0]))
-            elif rank in (rA, rB):
-                mine = sampler.pt_export(A if rank == rA else A + 1)
-                send = torch.from_numpy(mine)
-                if device is not None:
-                    send = send.to(device)
-                recv = torch.empty_like(send)
-                peer = rB if rank == rA else rA
-                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]):
-                    req.wait()
-                swaps.append((A, sampler.pt_import(A, u, recv.cpu().numpy())[0]))
-        sampler.end_iteration()
-    return swaps
+
+    def exchange(my_chain, peer_chain, send):
+        peer = peer_chain // chains_per_rank
+        t_send = torch.from_numpy(np.ascontiguousarray(send))
+        if device is not None:
+            t_send = t_send.to(device)
+        t_recv = torch.empty_like(t_send)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, t_send, peer), dist.P2POp(dist.irecv, t_recv, peer)]):
+            req.wait()
+        return t_recv.cpu().numpy()
+    return exchange
+
+
+def run_sharded(sampler, n_iter, dist, rank, world, chains_per_rank, device=None):
+    """n_iter iterations of a sharded run (the loop itself runs in the library): MH step on the local chains, then the
+    parallel-tempering attempt; a boundary pair costs one neighbour send/recv each way.  Returns [(A, swapped)] for
+    the attempts this rank took part in."""
+    _, _, swaps = sampler.run_sharded(n_iter, neighbour_exchange(dist, chains_per_rank, device), history=True)
+    return [(int(v) // 2, bool(v & 1)) for v in swaps if v >= 0]

@@ -49,22 +49,19 @@ def run_phase_sharded(setup, evaluator, dist, rank, world, seed, device=None, re
             raise SetupError(rc, "tamcmc_outputs_create", "see stderr")
     lib.tamcmc_outputs_push_block.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 15
     cap = min(Nbuffer, max(1, Nsamples - it0))
-    b_vars, b_stat, b_moved = np.empty((cap, nloc, nv)), np.empty((cap, 3, nloc)), np.empty((cap, nloc))
-    b_pt = np.empty((cap, 4))                      # attempted, chain A, Pswitch (nan = not an owner), switched (-1 = unknown)
-    sums = [np.zeros(nloc), np.zeros((nloc, nv)), np.zeros((nloc, nv, nv)), np.zeros((nloc, nv))]   # sigma, mu, covar, vars
-    k = 0
+    block = S.ShardBlock(smp, cap)                 # this rank's share of an output block, filled inside the library
     Pswap_last, swapped_last = 0.0, 0
 
-    def flush(n):
+    def flush():
         nonlocal Pswap_last, swapped_last
-        g_vars = _gather(dist, b_vars[:n], rank, world, device)
-        g_stat = _gather(dist, b_stat[:n], rank, world, device)
-        g_moved = _gather(dist, b_moved[:n], rank, world, device)
-        g_pt = _gather(dist, b_pt[:n], rank, world, device)
+        n = block.count()
+        g_vars = _gather(dist, block.data("vars"), rank, world, device)
+        g_stat = _gather(dist, block.data("stat"), rank, world, device)
+        g_moved = _gather(dist, block.data("moved"), rank, world, device)
+        g_pt = _gather(dist, block.data("pt"), rank, world, device)
         last = [_gather(dist, smp.get(w), rank, world, device) for w in ("vars", "sigma", "mu", "covarmat")]
-        g_sums = [_gather(dist, s_, rank, world, device) for s_ in sums]
-        for s_ in sums:
-            s_[...] = 0.0
+        g_sums = [_gather(dist, block.data(w), rank, world, device) for w in ("sum_sigma", "sum_mu", "sum_covar", "sum_vars")]
+        block.reset()
         if rank != 0:
             return
         vars_all = np.ascontiguousarray(np.concatenate(list(g_vars), axis=1))                     # [n, N, nv]
@@ -87,49 +84,20 @@ def run_phase_sharded(setup, evaluator, dist, rank, world, seed, device=None, re
         if rc != IO_OK:
             raise SetupError(rc, "tamcmc_outputs_push_block", lib.tamcmc_outputs_error(out).decode(errors="replace"))
 
-    import torch
-    for i in range(smp.iteration(), Nsamples):
-        if progress is not None and rank == 0 and i % Nbuffer == 0:
+    # the iteration loop runs inside the library (tamcmc_sampler_run_sharded); Python is entered once per boundary-pair
+    # exchange and once per block of Nbuffer samples
+    exchange = S.neighbour_exchange(dist, nloc, device)
+    i = smp.iteration()
+    while i < Nsamples:
+        if progress is not None and rank == 0:
             progress(i, Nsamples)
-        smp.mh_step()
-        att, A, r, sw = 0.0, -1.0, np.nan, -1.0
-        if smp.pt_due():
-            A, u = smp.pt_draw()                          # same values on every rank (replicated random stream)
-            att = 1.0
-            rA, rB = A // nloc, (A + 1) // nloc
-            if rA == rB:
-                if rank == rA:
-                    s2, r = smp.pt_local(A, u)
-                    sw = float(s2)
-            elif rank in (rA, rB):
-                send = torch.from_numpy(smp.pt_export(A if rank == rA else A + 1))
-                if device is not None:
-                    send = send.to(device)
-                recv = torch.empty_like(send)
-                peer = rB if rank == rA else rA
-                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]):
-                    req.wait()
-                s2, r = smp.pt_import(A, u, recv.cpu().numpy())
-                sw = float(s2)
-        b_vars[k] = smp.get("vars")
-        b_stat[k, 0], b_stat[k, 1], b_stat[k, 2] = smp.get("logL"), smp.get("logPrior"), smp.get("logPost")
-        b_moved[k] = smp._moved() if hasattr(smp, "_moved") else _moved(smp)
-        b_pt[k] = (att, A, r, sw)
-        for s_, w in zip(sums, ("sigma", "mu", "covarmat", "vars")):
-            s_ += smp.get(w)
-        k += 1
-        smp.end_iteration()
-        if k == cap or i == Nsamples - 1:
-            flush(k)
-            k = 0
+        done, _, _ = smp.run_sharded(min(cap, Nsamples - i), exchange, block=block)
+        i += done
+        flush()
+    block.close()
     if rank == 0:
         if progress is not None:
             progress(Nsamples, Nsamples)
         lib.tamcmc_outputs_destroy(out)
     return smp
 
-
-def _moved(smp):
-    out = np.empty(smp.nloc)
-    smp._check(smp._lib.tamcmc_sampler_get(smp._h, 10, out.ctypes.data_as(C.POINTER(C.c_double)), out.size), "tamcmc_sampler_get")
-    return out

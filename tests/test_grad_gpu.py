@@ -69,10 +69,12 @@ def test_gradient_full_size_is_reproducible(accel_mod, orc):
         acc.set_vars(w["index_to_relax"])
         L1, _, g1 = acc.eval_batch(P, T, grad=True)
         L2, _, g2 = acc.eval_batch(P, T, grad=True)
+        L0, _, g0 = acc.eval_batch(P, np.ones(8), grad=True)
     assert np.array_equal(g1, g2) and np.array_equal(L1, L2)
     assert np.all(np.isfinite(g1))
-    # tempering scales the gradient like the likelihood
-    assert np.allclose(g1[3] * T[3], g1[3] * T[3])
+    # tempering scales the gradient like the likelihood: g(T) * T == g(T = 1)  (model_def.cpp:302)
+    assert np.allclose(g1 * T[:, None], g0, rtol=1e-13, atol=0)
+    assert np.allclose(L1 * T, L0, rtol=1e-13, atol=0)
 
 
 def test_gradient_on_polynomial_background_tiles(accel_mod, orc, monkeypatch):

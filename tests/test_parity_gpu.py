@@ -334,6 +334,36 @@ def test_more_than_64_multiplets(accel_mod, orc):
     assert np.array_equal(gp[0], g[0][cols])
 
 
+def test_fused_launch_many_chains_changing_params(accel_mod, orc, monkeypatch):
+    """The fused launch reads the records it has just written through the scalar cache, and neighbouring chains' records
+    share cache lines (tamcmc_fused.hip): thousands of one-tile chains, parameters changing from call to call, must
+    stay bit-identical to the two-launch path (which has a kernel boundary between writer and reader)."""
+    w = W.any_model(11, Nx=600, trunc_c=20.0)
+    y = spectrum_for(orc, w)
+    n = 4096
+    T = np.tile(synth.temperatures(8), n // 8)
+    batches = [W.perturbed(w, n, scale=0.002 * (k + 1), seed=50 + k) for k in range(3)]
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TAMCMC_FUSED", fused)
+        with accel_mod.Accel(11, w["plength"], w["x"], y) as acc:
+            assert acc.geometry()["tiles"] == 1
+            acc.set_vars(w["index_to_relax"])
+            out = []
+            for P in batches:                       # same context: the records of the previous call are still in memory
+                L, st = acc.eval_batch(P, T)
+                Lg, stg, g = acc.eval_batch(P, T, grad=True)
+                out.append((L, st, Lg, stg, g))
+        res[fused] = out
+    for a, b in zip(res["1"], res["0"]):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    sel = np.arange(0, n, 257)
+    rL, rst = orc.generate_batch(11, w["plength"], w["x"], y, batches[2][sel], T[sel])
+    assert np.array_equal(res["1"][2][1][sel], rst)
+    check_logL(res["1"][2][0][sel], rL)
+
+
 @pytest.mark.parametrize("Nx", [973, 2048, 400])
 def test_fused_small_grid_launch_equals_two_launches(accel_mod, orc, monkeypatch, Nx):
     """Grids of <= 2048 bins are one tile per chain, and the prologue and the evaluation then share a launch
