@@ -54,6 +54,8 @@ typedef struct tamcmc_ctx tamcmc_ctx;
 #define TAMCMC_CHAIN_NAN           1  /* logL is NaN: legal, means "reject" (MALA.cpp:475,507-509)            */
 #define TAMCMC_CHAIN_EMPTY_WINDOW  2  /* a truncation window is empty: the reference would exit(EXIT_FAILURE),
                                          build_lorentzian.cpp:428-443; logL is set to NaN                      */
+#define TAMCMC_CHAIN_INTERNAL      3  /* internal consistency check of the tile balancer failed (never expected);
+                                         logL is set to NaN                                                    */
 
 /* Replaces: Config::setup() handing `Data` (data.h:24-36) + the integer switches
  * (config.cpp:95-98) to the Model_def constructor (model_def.cpp:27-55).

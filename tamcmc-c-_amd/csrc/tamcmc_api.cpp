@@ -31,14 +31,15 @@ static thread_local char g_hip_err[256] = "";
 struct tamcmc_ctx {
     int device = 0;
     TmLayout L{};
-    // Tile geometry (TM_TILE_U0 in tamcmc_dev.h): the grid is cut into `units` sub-blocks of 256*KU bins; tiles alternate
-    // between S and S2 sub-blocks.  Sg also bounds the LDS of the gradient kernel's second pass (8 bytes per bin).
-    int K = 4, S = 4, S2 = 1;      // likelihood only: KU bins in flight per thread; tiles of S / S2 sub-blocks of 1024 bins
-    int Kg = 2, Sg = 8, Sg2 = 8;   // with gradient partials: 2 bins in flight; tiles of Sg / Sg2 sub-blocks of 512 bins (32 KB of LDS)
-    int units = 0, units_g = 0;    // sub-blocks in the grid at K / Kg
-    int tiles_cap = 0, tiles_g_cap = 0;   // tiles of the two geometries (buffers are sized for them)
+    // Geometry (tamcmc_dev.h): units of 512 bins, cells of 8 units, tiles_l / tiles_g tiles per chain for the likelihood-only
+    // and the gradient launch -- functions of the grid alone; a chain's tile BOUNDARIES are chosen by the setup kernel.
+    int units = 0, cells = 0;
+    int tiles_l = 1, tiles_g = 1;
+    int tiles_max = 1;
+    int equal_cost = 0;            // TAMCMC_EQUAL_COST=1: per-chain tile boundaries of equal cost instead of equal length
+    int prio = 0;                  // TAMCMC_PRIO=1: issue priority by launch rank (s_setprio)
+    TmCostModel cost_l{60, 5, 9, 0}, cost_g{110, 13, 24, 0};   // VALU instructions per bin: c0 + sum(a * ncomp + b) (TAMCMC_COST / TAMCMC_COST_GRAD)
     int last_tiles = 0;            // T of the most recent likelihood-only call (tamcmc_ctx_geometry)
-    int tiles_max = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // resident data
@@ -59,8 +60,9 @@ struct tamcmc_ctx {
     void *d_chain_rec = nullptr, *d_aux = nullptr;   // TmChain / TmMultFull records kept for the backward kernel
     double *d_wt = nullptr;        // [cap][2] {T, wscale} device copies written by the setup kernel
     int32_t *d_ticket = nullptr;   // [cap] arrival counters of the in-launch finalize (kept at zero between launches)
-    TmTileRec *d_trec = nullptr;   // [cap][tiles_max] tile descriptors
-    int32_t *d_tidx = nullptr;     // [cap][tiles_max][n_mult] active multiplet lists
+    TmCellRec *d_cell = nullptr;   // [cap][cells] background polynomials
+    TmTileHdr *d_thdr = nullptr;   // [cap][tiles_max] tile headers (per-chain boundaries)
+    TmActive *d_tidx = nullptr;    // [cap][tiles_max][n_mult] active multiplet lists
     double *d_model = nullptr;
     size_t model_cap = 0;
     // host-pointer entry point: pinned, device-mapped staging the kernels read / write directly over PCIe
@@ -173,7 +175,7 @@ static void free_batch(tamcmc_ctx *c)
     (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_hser); (void)hipFree(c->d_order); c->d_order = nullptr;
     (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
     (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
-    (void)hipFree(c->d_trec); (void)hipFree(c->d_tidx); c->d_trec = nullptr; c->d_tidx = nullptr;
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_thdr); (void)hipFree(c->d_tidx); c->d_cell = nullptr; c->d_thdr = nullptr; c->d_tidx = nullptr;
     (void)hipFree(c->d_ticket); c->d_ticket = nullptr;
     (void)hipFree(c->d_wt); c->d_wt = nullptr;
     c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_hser = nullptr;
@@ -201,13 +203,14 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMalloc(&c->d_wt, n * 2 * sizeof(double)));
     TM_HIP(hipMalloc(&c->d_ticket, n * sizeof(int32_t)));
     TM_HIP(hipMemset(c->d_ticket, 0, n * sizeof(int32_t)));
-    TM_HIP(hipMalloc(&c->d_trec, n * c->tiles_max * sizeof(TmTileRec)));
-    TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(int32_t)));
+    TM_HIP(hipMalloc(&c->d_cell, n * c->cells * sizeof(TmCellRec)));
+    TM_HIP(hipMalloc(&c->d_thdr, n * c->tiles_max * sizeof(TmTileHdr)));
+    TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(TmActive)));
     TM_HIP(hipMalloc(&c->d_order, n * c->tiles_max * sizeof(int32_t)));
     if (g) {
-        TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g_cap * nm * TM_GSLOTS * sizeof(double)));
-        TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g_cap * TM_NSLOTS * sizeof(double)));
-        TM_HIP(hipMalloc(&c->d_hser, n * c->tiles_g_cap * TM_MAXH * TM_HSER * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g * nm * TM_GSLOTS * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g * 2 * TM_NSLOTS * sizeof(double)));
+        TM_HIP(hipMalloc(&c->d_hser, n * c->cells * TM_MAXH * TM_HSER * sizeof(double)));
         TM_HIP(hipMalloc(&c->d_chain_rec, n * tm_sizeof_chain_rec()));
         TM_HIP(hipMalloc(&c->d_aux, n * nm * tm_sizeof_aux()));
     }
@@ -229,7 +232,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
 {
     if (!out) return TAMCMC_E_INVALID;
     *out = nullptr;
-    if (!plength || !x || !y || Nx < 2 || Nx > 0x7fffff00LL) return TAMCMC_E_INVALID;
+    if (!plength || !x || !y || Nx < 2 || Nx > (1LL << 28)) return TAMCMC_E_INVALID;   // 32-bit byte offsets in the eval kernel (the reference reads at most 1e6 rows, config.cpp:531)
     int rc = model_supported(model_case);
     if (rc != TAMCMC_OK) return rc;
     if (likelihood_case != 0 && likelihood_case != 1) return TAMCMC_E_UNKNOWN_MODEL;
@@ -247,36 +250,32 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
         const char *e = getenv(name);
         if (e) { int v = atoi(e); if (v >= lo && v <= hi) *dst = v; }
     };
-    env_int("TAMCMC_KU", 1, 4, &c->K);
-    env_int("TAMCMC_S", 1, 64, &c->S);
-    env_int("TAMCMC_KU_GRAD", 1, 4, &c->Kg);
-    env_int("TAMCMC_S_GRAD", 1, 16, &c->Sg);
-    if (getenv("TAMCMC_S")) c->S2 = c->S;                // a size given alone means uniform tiles
-    if (getenv("TAMCMC_S_GRAD")) c->Sg2 = c->Sg;
-    env_int("TAMCMC_S2", 1, 64, &c->S2);
-    env_int("TAMCMC_S2_GRAD", 1, 16, &c->Sg2);
+    // Developer switches (documented in include/tamcmc_accel.h); none of them changes a result beyond rounding.
     { int v = 0; env_int("TAMCMC_BG_EXACT", 0, 1, &v); c->L.bg_exact = v; }
     env_int("TAMCMC_ORDER", 0, 2, &c->order_mode);
     env_int("TAMCMC_FUSED", 0, 1, &c->fuse);
-    if (c->K == 3) c->K = 4;
-    if (c->Kg == 3) c->Kg = 2;
+    env_int("TAMCMC_EQUAL_COST", 0, 1, &c->equal_cost);
+    env_int("TAMCMC_PRIO", 0, 1, &c->prio);
+    auto env_cost = [](const char *name, TmCostModel *m) {
+        const char *e = getenv(name);
+        int c0, a, b;
+        if (e && sscanf(e, "%d,%d,%d", &c0, &a, &b) == 3 && c0 >= 1 && c0 <= 10000 && a >= 0 && a <= 1000 && b >= 0 && b <= 1000) { m->c0 = c0; m->a = a; m->b = b; }
+    };
+    env_cost("TAMCMC_COST", &c->cost_l);
+    env_cost("TAMCMC_COST_GRAD", &c->cost_g);
     {
-        const int64_t UB = (int64_t)TM_THREADS * c->K, UBg = (int64_t)TM_THREADS * c->Kg;
-        c->units = (int)((Nx + UB - 1) / UB);
-        c->units_g = (int)((Nx + UBg - 1) / UBg);
-        // Short grids get smaller tiles, so that a chain still spreads over ~10 workgroups (a workgroup's run time is
-        // the floor of the launch: at 1e4 bins the defaults above would take 59 us per gradient step, these take 36-40).
-        // A function of the grid alone, like everything else about the geometry.
-        // And the shortest grids (<= 2048 bins, e.g. the ~1000-bin slices of a local fit) are one tile: then the
-        // prologue and the evaluation share a launch (tamcmc_fused.hip), which is what counts when a step is ~2 us of work.
-        if (!getenv("TAMCMC_S")) { const int s = c->units <= 2 ? c->units : c->units / 10; if (s < c->S) c->S = s < 1 ? 1 : s; }
-        if (!getenv("TAMCMC_S_GRAD")) { const int s = c->units_g <= 4 ? c->units_g : c->units_g / 10; if (s < c->Sg) { c->Sg = s < 1 ? 1 : s; c->Sg2 = c->Sg; } }
-        if (c->S2 > c->S) c->S2 = c->S;
-        if (c->Sg2 > c->Sg) c->Sg2 = c->Sg;
-        c->tiles_cap = tm_tile_count(c->units, c->S, c->S2);
-        c->tiles_g_cap = tm_tile_count(c->units_g, c->Sg, c->Sg2);
+        c->units = tm_units(Nx);
+        c->cells = tm_cells(c->units);
+        c->tiles_l = tm_tiles(c->units, 0);
+        c->tiles_g = tm_tiles(c->units, 1);
+        // a tile count given by hand must still keep every tile within TM_TILE_MAXU units
+        const int tmin = (c->units + TM_TILE_MAXU - 1) / TM_TILE_MAXU + (c->units > TM_TILE_MAXU ? 1 : 0);
+        if (c->units > 4) {
+            env_int("TAMCMC_TILES", tmin, 1 << 20, &c->tiles_l);
+            env_int("TAMCMC_TILES_GRAD", tmin, 1 << 20, &c->tiles_g);
+        }
     }
-    c->tiles_max = c->tiles_cap > c->tiles_g_cap ? c->tiles_cap : c->tiles_g_cap;
+    c->tiles_max = c->tiles_l > c->tiles_g ? c->tiles_l : c->tiles_g;
 
     auto fail = [&](int code) { tamcmc_ctx_destroy(c); return code; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(TAMCMC_E_NODEVICE);
@@ -462,7 +461,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
 {
     if (!c) return TAMCMC_E_INVALID;
     const int T = c->last_tiles > 0 ? c->last_tiles : pick_tiles(c, 64, false);
-    if (bins_per_tile) *bins_per_tile = TM_THREADS * c->K * c->S;   // the largest tile
+    if (bins_per_tile) *bins_per_tile = TM_UNIT_BINS * TM_TILE_MAXU;   // the largest tile the balancer can make
     if (tiles) *tiles = T;
     if (threads_per_block) *threads_per_block = TM_THREADS;
     if (n_multiplets) *n_multiplets = c->L.n_mult;
@@ -473,7 +472,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
 // of chains evaluated beside it (a sharded run and a single-process run have to produce bit-identical chains).
 static int pick_tiles(const tamcmc_ctx *c, int /*Nchains*/, bool grad)
 {
-    return grad ? c->tiles_g_cap : c->tiles_cap;
+    return grad ? c->tiles_g : c->tiles_l;
 }
 
 // Enqueue setup -> eval (-> backward) for device-resident inputs.
@@ -484,31 +483,28 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     // several spectra resident: every chain of the batch must have been told which one it is fitted to (a batch longer
     // than the map used to fall back to spectrum 0 for all chains -- silently the wrong data)
     if (c->nspec > 1 && (c->d_spec == nullptr || Nchains > c->spec_n)) return TAMCMC_E_INVALID;
-    const int K = grad ? c->Kg : c->K;
-    const int units = grad ? c->units_g : c->units;
+    const int units = c->units, cells = c->cells;
     const int tiles = pick_tiles(c, Nchains, grad);
-    const int big = grad ? c->Sg : c->S, small = grad ? c->Sg2 : c->S2;
     if (!grad) c->last_tiles = tiles;
     TmEvalArgs a{};
     a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
     a.spec = (c->nspec > 1) ? c->d_spec : nullptr;
-    a.mult = c->d_mult; a.noise = c->d_noise; a.trec = c->d_trec; a.tidx = c->d_tidx; a.wt = c->d_wt;
+    a.mult = c->d_mult; a.noise = c->d_noise; a.cell = c->d_cell; a.thdr = c->d_thdr; a.tidx = c->d_tidx; a.wt = c->d_wt;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
     a.row_of_chain = d_rows; a.model_out = d_model;
     a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
-    a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.likelihood_case = c->L.likelihood_case;
+    a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.cells = cells; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
-    a.units = units; a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0;
+    a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio;
     if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
-    a.tile_big = big; a.tile_small = small;
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     // one tile per chain (short grids): prologue and evaluation share a launch
     const bool fused = (tiles == 1) && c->fuse != 0;
     int rc = 0;
     if (!fused) {
-        rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, TM_THREADS * K, units, big, small, c->d_mult, c->d_noise,
-                             c->d_trec, c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr, grad ? c->d_hser : nullptr,
-                             c->order_mode == 2 ? c->d_order : nullptr, c->stream);
+        rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, units, cells, tiles, c->equal_cost, grad ? c->cost_g : c->cost_l,
+                             c->d_mult, c->d_noise, c->d_cell, c->d_thdr, c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr,
+                             grad ? c->d_hser : nullptr, a.order_mode == 2 ? c->d_order : nullptr, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }
     if (c->profile) {
@@ -524,9 +520,9 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
         f.params = d_params; f.Tcoefs = d_T;
         f.chain_rec = grad ? c->d_chain_rec : nullptr; f.aux = grad ? c->d_aux : nullptr; f.hser = grad ? c->d_hser : nullptr;
         f.p_doubles = (c->L.Nparams + 1) & ~1;
-        rc = tm_launch_fused(c->L, f, a, Nchains, K, grad, c->stream);
+        rc = tm_launch_fused(c->L, f, a, Nchains, grad, c->stream);
     } else {
-        rc = tm_launch_eval(a, Nchains, K, grad, c->stream);
+        rc = tm_launch_eval(a, Nchains, grad, c->stream);
     }
     if (rc != 0) {
         snprintf(g_hip_err, sizeof(g_hip_err), "eval launch -> %s", hipGetErrorString((hipError_t)rc));
@@ -540,9 +536,9 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, TM_THREADS * K, units, big, small, d_params, c->d_wt, c->d_chain_rec, c->d_aux,
-                                c->d_noise, c->d_part, c->d_gmult, c->d_gnoise, c->d_trec, c->d_hser, c->Nvars, c->d_relax, d_grad, d_logL,
-                                d_status, c->stream);
+        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, d_params, c->d_wt, c->d_chain_rec, c->d_aux, c->d_noise, c->d_part,
+                                c->d_gmult, c->d_gnoise, c->d_cell, c->d_thdr, c->d_hser, c->Nvars, c->d_relax, d_grad, d_logL, d_status,
+                                c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }
     return TAMCMC_OK;

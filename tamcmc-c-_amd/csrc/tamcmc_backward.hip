@@ -36,8 +36,7 @@ __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + 
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
 #define TM_BW_THREADS 256
-__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int ub_shift, int big, int small,
-                                                             unsigned long long magic_p,
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int cells,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmChain *__restrict__ chain_rec,
@@ -46,7 +45,8 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                                                              const double *__restrict__ part,
                                                              const double *__restrict__ gmult,
                                                              const double *__restrict__ gnoise,
-                                                             const TmTileRec *__restrict__ trec, const double *__restrict__ hser,
+                                                             const TmCellRec *__restrict__ cell, const TmTileHdr *__restrict__ thdr,
+                                                             const double *__restrict__ hser,
                                                              int Nvars, const int32_t *__restrict__ relax,
                                                              double *__restrict__ grad,
                                                              double *__restrict__ logL, int32_t *__restrict__ status,
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     int *pair_idx = reinterpret_cast<int *>(s_adjh + (size_t)nm * TM_MAXM);  // [npairs_max]
     // per-multiplet records: staged in LDS when they fit (coalesced copy), else read in place from global
     constexpr int AUXD = (int)(sizeof(TmMultFull) / sizeof(double));
-    double *s_aux = reinterpret_cast<double *>(pair_idx + ((npairs_max + 1) & ~1));
+    int *s_u = pair_idx + ((npairs_max + 1) & ~1);             // [tiles + 1] first unit of every tile, then the end of the last
+    double *s_aux = reinterpret_cast<double *>(s_u + ((tiles + 2) & ~1));
     const TmMultFull *auxp = aux + (size_t)chain * nm;
     if (aux_in_lds) {
         for (int e = tid; e < nm * AUXD; e += TM_BW_THREADS) s_aux[e] = reinterpret_cast<const double *>(auxp)[e];
@@ -81,15 +82,21 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     }
 
     for (int e = tid; e < npairs_max; e += TM_BW_THREADS) { pair_idx[e] = -1; pair_val[e] = 0.0; }
+    for (int t = tid; t < tiles; t += TM_BW_THREADS) {
+        const TmTileHdr H = thdr[(size_t)chain * tiles + t];
+        s_u[t] = H.u0;
+        if (t == tiles - 1) s_u[tiles] = H.u1;
+    }
     for (int e = tid; e < nm * TM_NSHARED; e += TM_BW_THREADS) shared_adj[e] = 0.0;
     if (L.family != TM_FAM_GAUSS)
         for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_BW_THREADS)
             reinterpret_cast<double *>(&C)[e] = reinterpret_cast<const double *>(chain_rec + chain)[e];
-    // noise partials: wave 1, one lane per tile (stride 64).  On a tile whose background was evaluated as a polynomial
-    // the eval kernel left the moments m_j = sum w dl^j (slot 9: j = 0, slot j-1: j = 1..9); with profile h's series
-    // u_h = sum c_j dl^j (setup kernel) and u(1-u) = -(1/p) du/d(dl) = sum d_j dl^j, d_j = -(j+1) c_{j+1}/p:
+    // noise partials: wave 1, one lane per (tile, cell part) (stride 64).  A tile meets at most two cells and leaves one
+    // set of partials per cell.  On a cell whose background was evaluated as a polynomial the eval kernel left the
+    // moments m_j = sum w dl^j (slot 9: j = 0, slot j-1: j = 1..9); with profile h's series u_h = sum c_j dl^j (setup
+    // kernel) and u(1-u) = -(1/p) du/d(dl) = sum d_j dl^j, d_j = -(j+1) c_{j+1}/p:
     //   sum w u = sum c_j m_j,  sum w u(1-u) = sum d_j m_j,  sum w u(1-u)(lt + log x) = (lt + lxc) sum d_j m_j + sum d_j m_{j+1}.
-    // Other tiles hold those three sums already.  Lanes then meet in LDS and are summed in a fixed order.
+    // Other cells hold those three sums already.  Lanes then meet in LDS and are summed in a fixed order.
     if (tid >= 64 && tid < 128) {
         const int lane = tid - 64;
         double acc[TM_NSLOTS];
@@ -97,12 +104,17 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         for (int sl = 0; sl < TM_NSLOTS; sl++) acc[sl] = 0.0;
         const TmNoise *nz = noise + chain;
         const int nh = nz->nh;
-        for (int t = lane; t < tiles; t += 64) {
-            const double *G = gnoise + ((size_t)chain * tiles + t) * TM_NSLOTS;
+        for (int it = lane; it < 2 * tiles; it += 64) {
+            const int t = it >> 1, part = it & 1;
+            const TmTileHdr H = thdr[(size_t)chain * tiles + t];
+            if (H.u1 <= H.u0) continue;
+            const int ce = (H.u0 >> TM_CELL_SHIFT) + part;
+            if (ce > ((H.u1 - 1) >> TM_CELL_SHIFT)) continue;          // the tile lies in one cell: no second part
+            const double *G = gnoise + (((size_t)chain * tiles + t) * 2 + part) * TM_NSLOTS;
             double g[TM_NSLOTS];
 #pragma unroll
             for (int sl = 0; sl < TM_NSLOTS; sl++) g[sl] = G[sl];
-            const TmTileRec *R = trec + (size_t)chain * tiles + t;
+            const TmCellRec *R = cell + (size_t)chain * cells + ce;
             if (nh > 0 && R->npoly != 0) {
                 double m[TM_HSER];
                 m[0] = g[3 * TM_MAXH];
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #pragma unroll
                 for (int h = 0; h < TM_MAXH; h++) {
                     if (h < nh) {
-                        const double *c = hser + (((size_t)chain * tiles + t) * TM_MAXH + h) * TM_HSER;
+                        const double *c = hser + (((size_t)chain * cells + ce) * TM_MAXH + h) * TM_HSER;
                         const double ip = -1.0 / nz->p[h];
                         double k0 = 0.0, k1 = 0.0, k2 = 0.0;
 #pragma unroll
@@ -175,14 +187,18 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const TmMultFull &M = auxp[j];
         double acc = 0.0;
         if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
-            // tiles whose sub-blocks meet the window's sub-blocks [ua, ub]
-            // (UB is a power of two; the quotient uses a host-made reciprocal: exact for operands < 2^20)
-            const int ua = M.imin >> ub_shift, ub = (M.imax - 1) >> ub_shift;
-            const int pair = (int)(((unsigned long long)ua * magic_p) >> 40);      // ua / (big + small)
-            int t0 = 2 * pair + ((ua - pair * (big + small) >= big) ? 1 : 0);
-            if (t0 > tiles - 1) t0 = tiles - 1;
-            for (int t = t0; t < tiles && TM_TILE_U0(t, big, small) <= ub; t++)
-                acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
+            // tiles whose units meet the window's units [ua, ub] (the multiplet is on their active lists): the first one
+            // is the tile holding unit ua -- the last tile that starts at or before it (binary search over the tile
+            // starts; empty tiles share a start with their successor and are passed over by taking the last)
+            const int ua = M.imin >> TM_UNIT_SHIFT, ub = (M.imax - 1) >> TM_UNIT_SHIFT;
+            int lo = 0, hi = tiles - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_u[mid] <= ua) lo = mid; else hi = mid - 1;
+            }
+            for (int t = lo; t < tiles && s_u[t] <= ub; t++)
+                if (s_u[t + 1] > s_u[t] && s_u[t + 1] > ua)
+                    acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
         }
         s_G[item] = acc;
     }
@@ -483,18 +499,19 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     for (int k = tid; k < Nvars; k += TM_BW_THREADS) grad[(size_t)chain * Nvars + k] = s_row[k];
 }
 
-int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units, int big, int small, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
-                       const double *d_part, const double *d_gmult, const double *d_gnoise,
-                       const TmTileRec *d_trec, const double *d_hser,
-                       int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
-                       void *stream)
+                       const double *d_part, const double *d_gmult, const double *d_gnoise, const TmCellRec *d_cell,
+                       const TmTileHdr *d_thdr, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad,
+                       double *d_logL, int32_t *d_status, void *stream)
 {
     const int nm = L.n_mult;
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
+    if (units < 1 || cells < 1 || tiles < 1) return (int)hipErrorInvalidValue;
     size_t lds = ((size_t)L.Nparams + (size_t)Nvars) * sizeof(double) + (size_t)npairs_max * sizeof(double) +
-                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + (size_t)((npairs_max + 1) & ~1) * sizeof(int);
+                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + (size_t)((npairs_max + 1) & ~1) * sizeof(int) +
+                 (size_t)((tiles + 2) & ~1) * sizeof(int);
     const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);
     const int aux_in_lds = (lds + aux_bytes <= 100 * 1024) ? 1 : 0;
     if (aux_in_lds) lds += aux_bytes;
@@ -504,14 +521,8 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    int ub_shift = 0;
-    while ((1 << ub_shift) < unit_bins) ub_shift++;
-    if ((1 << ub_shift) != unit_bins || big < 1 || small < 1 || units < 1 || units >= (1 << 20)) return (int)hipErrorInvalidValue;
-    const int tiles = tm_tile_count(units, big, small);
-    const unsigned long long magic_p = ((1ULL << 40) + (unsigned long long)(big + small) - 1) / (unsigned long long)(big + small);
-    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles,
-                       ub_shift, big, small, magic_p, d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec),
-                       static_cast<const TmMultFull *>(d_aux), d_noise, d_part, d_gmult, d_gnoise, d_trec, d_hser, Nvars,
-                       d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
+    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles, cells,
+                       d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec), static_cast<const TmMultFull *>(d_aux), d_noise,
+                       d_part, d_gmult, d_gnoise, d_cell, d_thdr, d_hser, Nvars, d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();
 }

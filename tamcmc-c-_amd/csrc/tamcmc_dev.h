@@ -5,9 +5,11 @@
 //   params[Nchains][Nparams], Tcoefs[Nchains]                                 per call (or caller-resident)
 //   mult[Nchains][n_mult]   : TmMult  -- per-chain multiplet table written by the setup kernel
 //   noise[Nchains]          : TmNoise -- Harvey / white-noise / Gaussian terms per chain
+//   cell[Nchains][cells]    : TmCellRec -- background polynomial per fixed 4096-bin cell
+//   thdr[Nchains][tiles]    : TmTileHdr -- per-chain tile boundaries (equal-cost tiles), active-multiplet counts
 //   part[Nchains][tiles][2] : per-tile partial sums of the likelihood (fixed-order reduction)
-//   gmult[Nchains][tiles][n_mult][TM_GSLOTS], gnoise[Nchains][tiles][TM_NSLOTS] : gradient partials
-//   hser[Nchains][tiles][TM_MAXH][TM_HSER] : per-profile series of u = 1/(1+t) in (log x - lxc), gradient path only
+//   gmult[Nchains][tiles][n_mult][TM_GSLOTS], gnoise[Nchains][tiles][2][TM_NSLOTS] : gradient partials
+//   hser[Nchains][cells][TM_MAXH][TM_HSER] : per-profile series of u = 1/(1+t) in (log x - lxc), gradient path only
 //   logL[Nchains], status[Nchains] (int32), grad[Nchains][Nvars]
 #pragma once
 #include <stddef.h>
@@ -42,7 +44,7 @@ struct TmLayout {
     int32_t nharvey;      // Harvey profiles evaluated (0 for local models, models.cpp:1818)
     int32_t likelihood_case;
     int32_t Nx;
-    int32_t bg_exact;     // developer switch (env TAMCMC_BG_EXACT=1): no in-tile polynomials, exp() per bin and profile
+    int32_t bg_exact;     // developer switch (env TAMCMC_BG_EXACT=1): no in-cell polynomials, exp() per bin and profile
     double  x0, xlast, step;  // x[0], x[Nx-1], x[1]-x[0] (models.cpp:489)
     double  like_p;           // (double)(long)likelihood_params
 };
@@ -74,55 +76,119 @@ struct TmNoise {
 static_assert(sizeof(TmNoise) == 120, "TmNoise layout");
 #define TM_NOISE_DOUBLES 15
 
-// Per (chain, tile) descriptor written by the setup kernel and read by the eval kernel through scalar loads:
-// everything a tile needs besides the multiplet records themselves.
-struct TmTileRec {
+// ---- geometry --------------------------------------------------------------------------------------------
+// The grid is cut into UNITS of TM_UNIT_BINS = 512 bins (two rows of 256: thread t of a workgroup owns bins
+// unit*512 + k*256 + t, k = 0, 1, so every load is a coalesced 8-byte-per-lane stream).
+// CELLS of TM_CELL_UNITS = 8 units (4096 bins) are a fixed function of the grid: each carries the background as a
+// polynomial in (log x - log x_centre) (and, for the gradient, the Harvey series the backward kernel needs).
+// TILES -- the work of one workgroup -- are runs of at most TM_TILE_MAXU consecutive units whose boundaries the setup
+// kernel chooses PER CHAIN so that every tile of a chain costs about the same (prefix sum of the per-unit cost the
+// chain's truncation windows imply): tile count and cell geometry depend on the grid only, a chain's boundaries on that
+// chain's own parameters only -- never on the batch -- so a chain's result does not change with the chains beside it.
+#define TM_UNIT_BINS 512
+#define TM_UNIT_SHIFT 9
+#define TM_CELL_UNITS 8
+#define TM_CELL_SHIFT 3
+#define TM_TILE_MAXU 8      // units per tile at most: 32 KB of gradient weights in LDS; a tile meets at most 2 cells
+#define TM_EQ_MAXU 4096     // grids of up to this many units (2M bins) get equal-cost tiles (cost prefix lives in LDS)
+
+// Per (chain, cell) record written by the setup kernel and read by the eval kernel through scalar loads.
+struct TmCellRec {
     double bg[TM_PDEG + 1];   // background N0 + sum_h H_h/(1 + t_h) as a polynomial in (log x - lxc)
-    double t0[TM_MAXH];       // t_h = (1e-3 tau_h x_c)^p_h at the tile centre
-    double lxc;               // log x at the tile centre
-    int32_t npoly;            // 1: polynomials valid on this tile (|p_h (log x - lxc)| <= 0.04, t0 finite), 0: use exp
-    int32_t nact;             // multiplets whose window meets the tile; their indices are tidx[0..nact)
+    double t0[TM_MAXH];       // t_h = (1e-3 tau_h x_c)^p_h at the cell centre
+    double lxc;               // log x at the cell centre
+    int32_t npoly;            // 1: polynomials valid on this cell (|p_h (log x - lxc)| <= 0.04, t0 finite), 0: use exp
+    int32_t pad;
 };
-static_assert(sizeof(TmTileRec) == 8 * (TM_PDEG + 1 + TM_MAXH + 2), "TmTileRec layout");
+static_assert(sizeof(TmCellRec) == 8 * (TM_PDEG + 1 + TM_MAXH + 2), "TmCellRec layout");
+
+// Per (chain, tile) header: the tile's units [u0, u1), the number of multiplets whose window meets it (their indices
+// are tidx[0..nact)) and its cost (launch-rank key).
+struct TmTileHdr {
+    int32_t u0, u1, nact, cost;
+};
+static_assert(sizeof(TmTileHdr) == 16, "TmTileHdr layout");
+
+// One entry of a tile's active list: the multiplet's index in the chain's table and -- so that the eval kernel can test
+// the window and pick the code path without waiting for the record itself -- its window and shape.  One 16-byte scalar load.
+struct TmActive {
+    int32_t idx;          // index into mult[chain][..]
+    int32_t imin, imax;   // truncation window [imin, imax)
+    int32_t shape;        // ncomp | (has_asym << 8)
+};
+static_assert(sizeof(TmActive) == 16, "TmActive layout");
+
+// Cost model of the tile balancer, in VALU instructions per bin: a unit costs c0 + sum over the multiplets whose window
+// meets it of (a * ncomp + b).
+struct TmCostModel {
+    int32_t c0, a, b, pad;
+};
 
 struct TmEvalArgs {
     const double *x, *y, *lx, *isig2;
     const TmMult *mult;
     const TmNoise *noise;
-    const TmTileRec *trec;      // [Nchains][tiles]
-    const int32_t *tidx;        // [Nchains][tiles][n_mult] active multiplet indices, table order
+    const TmCellRec *cell;      // [Nchains][cells]
+    const TmTileHdr *thdr;      // [Nchains][tiles]
+    const TmActive *tidx;       // [Nchains][tiles][n_mult] active multiplets, table order
     const int32_t *spec;        // NULL, or [Nchains]: which of the context's spectra (y, 1/sigma^2 blocks of Nx) a chain is fitted to
-    const double *wt;            // [Nchains][2] {Tcoefs[chain], p/T or 2/T} copied by the setup kernel into device memory
+    const double *wt;           // [Nchains][2] {Tcoefs[chain], p/T or 2/T} copied by the setup kernel into device memory
     double *part;               // [Nchains][tiles][2]
     double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL
-    double *gnoise;             // [Nchains][tiles][TM_NSLOTS] or NULL
+    double *gnoise;             // [Nchains][tiles][2][TM_NSLOTS] or NULL: one set per cell the tile meets (at most 2)
     int32_t *ticket;            // [Nchains] arrival counters (zero between launches) for the in-launch finalize, or NULL
     double *logL;               // [Nchains] outputs of the in-launch finalize (likelihood-only path)
     int32_t *status;
     const int32_t *row_of_chain;// NULL or [Nchains]: row of model_out to fill, -1 none
     double *model_out;
-    int32_t Nx, n_mult, tiles, likelihood_case;
+    int32_t Nx, n_mult, tiles, cells, likelihood_case;
     const int32_t *order;       // [Nchains][tiles] launch rank -> tile, costliest first (setup kernel), or NULL
-    int32_t units, order_mode;  // the grid is cut into `units` sub-blocks of 256*KU bins (see TM_TILE_U0 below)
-    int32_t tile_big, tile_small;   // sub-blocks of the even / odd tiles
+    int32_t order_mode;
+    int32_t prio;               // 1: issue priority by launch rank (s_setprio), 0: all workgroups alike
+    int32_t pad0;
     double like_p;
     unsigned long long tile_magic;   // ceil(2^40 / tiles): n / tiles == (n * tile_magic) >> 40 for n < 2^20 (slot -> tile rotation)
 };
 
-// Tile geometry.  The grid is cut into `units` sub-blocks of 256*KU bins; tiles alternate between `big` and `small`
-// sub-blocks: tile 2k starts at sub-block k*(big+small) and owns `big` of them, tile 2k+1 owns the `small` ones that
-// follow; the last tile is cut at `units`.  big == small gives uniform tiles.  Two sizes exist for the sake of the
-// launch's tail: tiles are launched costliest-first, so the small ones run last and the launch ends on short
-// workgroups (profiles/README.md).  The geometry depends on the grid only, never on the batch or the parameters.
-#define TM_TILE_U0(t, big, small) ((((int)(t)) >> 1) * ((int)(big) + (int)(small)) + ((((int)(t)) & 1) ? (int)(big) : 0))
-#define TM_TILE_S(t, big, small, units)                                                                              \
-    ((((((int)(t)) & 1) ? (int)(small) : (int)(big)) < (int)(units) - TM_TILE_U0(t, big, small))                      \
-         ? ((((int)(t)) & 1) ? (int)(small) : (int)(big))                                                             \
-         : (int)(units) - TM_TILE_U0(t, big, small))
-static inline int tm_tile_count(int units, int big, int small)
+static inline int tm_units(long long Nx) { return (int)((Nx + TM_UNIT_BINS - 1) / TM_UNIT_BINS); }
+static inline int tm_cells(int units) { return (units + TM_CELL_UNITS - 1) / TM_CELL_UNITS; }
+// Tile counts (a function of the grid only).  Grids of <= 4 units (2048 bins) are one tile (then the prologue and the
+// evaluation share a launch, tamcmc_fused.hip); short grids get ~10 tiles per chain (a workgroup's run time is the
+// floor of a launch); long grids 7 units per likelihood tile and 49/8 per gradient tile on average -- at 1e5 bins
+// (196 units) that is 28 and 32 tiles: with 64 chains, 1792 = 7 x 256 CUs and 2048 = 2 x 4 x 256 workgroups, whole
+// multiples of what is resident at once (7 and 4 waves per SIMD).  tiles * TM_TILE_MAXU > units always holds.
+static inline int tm_tiles(int units, int grad)
 {
-    const int P = big + small, n = units / P, rem = units - n * P;
-    return 2 * n + (rem > 0 ? 1 : 0) + (rem > big ? 1 : 0);
+    if (units <= 4) return 1;
+    if (units < 70) { const int s = units / 10 > 0 ? units / 10 : 1; return (units + s - 1) / s; }
+    return grad ? (units * 8 + 48) / 49 : (units + 6) / 7;
+}
+
+#if defined(__HIPCC__)
+#define TM_HD __host__ __device__
+#else
+#define TM_HD
+#endif
+// Equal-cost tile boundary t (0 < t < tiles) from the INCLUSIVE prefix `pre` of the unit costs (C = pre[units-1] the
+// total, cmin the cheapest unit): the smallest u in [0, units] with Q'(u) >= t/T of the total, where Q' is the prefix
+// of cost(u) + lambda and lambda >= 0 is the uniform surcharge that keeps every tile within S = TM_TILE_MAXU units:
+// with D = T S - U (> 0 by the tile count) and N = max(0, C - T S cmin), lambda = N / D gives
+//     (tile size - 1) * (cmin + lambda) < (C + lambda U) / T = S (cmin + lambda),   i.e. size <= S.
+// Integer arithmetic throughout (cross-multiplied, 64 bit: T <= 1024, D <= 8192, C < 2^31 / T), so the boundaries are
+// a pure function of the costs.  Shared by the setup kernel and tests/cpp/geometry_check.cpp.
+static inline TM_HD int tm_tile_bound(int t, int tiles, int units, const int *pre, long long C, long long cmin)
+{
+    const long long T = tiles, U = units, S = TM_TILE_MAXU;
+    const long long D = T * S - U;
+    const long long Nl = (C - T * S * cmin > 0) ? C - T * S * cmin : 0;
+    const long long rhs = (long long)t * (D * C + Nl * U);
+    int lo = 0, hi = units;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const long long q = (mid == 0) ? 0 : (long long)pre[mid - 1];
+        if (T * (D * q + Nl * mid) >= rhs) hi = mid; else lo = mid + 1;
+    }
+    return lo;
 }
 
 // What the fused small-grid launch (tamcmc_fused.hip) needs on top of TmEvalArgs: the inputs and the gradient-path
@@ -138,21 +204,22 @@ struct TmFusedArgs {
 extern "C++" {
 // launchers implemented in the .hip files
 struct ihipStream_t;
-// unit_bins / units / big / small: geometry of the eval launch that follows (the tile descriptors are built for it)
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
-                    int units, int big, int small, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
-                    void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */, double *d_hser /* may be NULL */,
-                    int32_t *d_order /* may be NULL */, void *stream);
+// units / cells / tiles: geometry of the eval launch that follows (tile headers and active lists are built for it);
+// equal_cost = 0 cuts every chain into tiles of equal length instead
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx,
+                    int units, int cells, int tiles, int equal_cost, TmCostModel cm, TmMult *d_mult, TmNoise *d_noise, TmCellRec *d_cell,
+                    TmTileHdr *d_thdr, TmActive *d_tidx, void *d_chain_rec /* may be NULL */, void *d_aux /* may be NULL */,
+                    double *d_hser /* may be NULL */, int32_t *d_order /* may be NULL */, void *stream);
 size_t tm_sizeof_chain_rec();
 size_t tm_sizeof_aux();
-int tm_launch_eval(const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
+int tm_launch_eval(const TmEvalArgs &a, int Nchains, bool grad, void *stream);
 // setup + eval in one launch; requires a.tiles == 1
-int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream);
+int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, bool grad, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
-int tm_launch_backward(const TmLayout &L, int Nchains, int unit_bins, int units, int big, int small, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
-                       const double *d_part, const double *d_gmult, const double *d_gnoise,
-                       const TmTileRec *d_trec, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad, double *d_logL, int32_t *d_status,
-                       void *stream);
+                       const double *d_part, const double *d_gmult, const double *d_gnoise, const TmCellRec *d_cell,
+                       const TmTileHdr *d_thdr, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad,
+                       double *d_logL, int32_t *d_status, void *stream);
 }
 #endif

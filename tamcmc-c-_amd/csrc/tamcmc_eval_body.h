@@ -14,9 +14,11 @@
 // operand -- no LDS read, no VGPRs for the record.  The table was written by the previous kernel (setup), so
 // it is invariant for this launch.
 typedef const __attribute__((address_space(4))) TmMult *TmMultK;
-typedef const __attribute__((address_space(4))) TmTileRec *TmTileRecK;
+typedef const __attribute__((address_space(4))) TmCellRec *TmCellRecK;
+typedef const __attribute__((address_space(4))) TmTileHdr *TmTileHdrK;
 typedef const __attribute__((address_space(4))) TmNoise *TmNoiseK;
 typedef const __attribute__((address_space(4))) int32_t *TmIdxK;
+typedef const __attribute__((address_space(4))) TmActive *TmActiveK;
 
 // 1/x for finite, normal, positive x: v_rcp_f64 + two Newton steps (no scaling / fix-up needed
 // because every denominator here is bounded away from the subnormal and overflow ranges).
@@ -95,23 +97,8 @@ __device__ __forceinline__ double tm_wave_sum(double v)   // lane 0 ends with th
     return v;
 }
 
-// exp(z) for |z| <= 0.04: Taylor degree 8, truncation error < 0.04^9/9! = 7e-19
-__device__ __forceinline__ double tm_exp_small(double z)
-{
-    double p = 1.0 / 40320.0;
-    p = __builtin_fma(p, z, 1.0 / 5040.0);
-    p = __builtin_fma(p, z, 1.0 / 720.0);
-    p = __builtin_fma(p, z, 1.0 / 120.0);
-    p = __builtin_fma(p, z, 1.0 / 24.0);
-    p = __builtin_fma(p, z, 1.0 / 6.0);
-    p = __builtin_fma(p, z, 0.5);
-    p = __builtin_fma(p, z, 1.0);
-    p = __builtin_fma(p, z, 1.0);
-    return p;
-}
-
-// Horner evaluation of the tile's background polynomial; the coefficients are SGPR operands (scalar loads)
-__device__ __forceinline__ double tm_poly(TmTileRecK tr, double z)
+// Horner evaluation of the cell's background polynomial; the coefficients are SGPR operands (scalar loads)
+__device__ __forceinline__ double tm_poly(TmCellRecK tr, double z)
 {
     double p = tr->bg[TM_PDEG];
 #pragma unroll
@@ -206,35 +193,106 @@ __device__ __forceinline__ double tm_mult_sum(double x2, const double (&nu2)[NC]
     return N * tm_rcp(Q);
 }
 
-// Forward: add multiplet `sm` (LDS) to acc[] for KU bins.
-template <int NC, int KU, bool ASYM>
-__device__ __forceinline__ void tm_accum_mult(TmMultK sm, const double (&x2)[KU], const int (&bi)[KU], double (&acc)[KU])
+// Forward: add multiplet `sm` to acc[] for KG bins.  edge (wave-uniform) = false: the whole group lies inside the
+// multiplet's window [imin, imax) and inside the grid, so no bin needs a test; edge = true: bins outside the window
+// (bi[k] = -1 marks a bin outside the grid) get nothing -- the reference adds the multiplet inside its window only
+// (build_lorentzian.cpp:423-427).  One copy of the arithmetic; the tests sit behind a scalar branch.
+template <int NC, int KG, bool ASYM>
+__device__ __forceinline__ void tm_accum_mult(TmMultK sm, const double (&x2)[KG], const int (&bi)[KG], double (&acc)[KG], const bool edge)
 {
+    // (the window itself is read from the record only on the edge path: rare, and the record is in flight anyway)
     double nu2[NC], hq[NC];
 #pragma unroll
     for (int m = 0; m < NC; m++) { nu2[m] = sm->nu2[m]; hq[m] = sm->hq[m]; }
     const double g2 = sm->g2;
-    const int imin = sm->imin, imax = sm->imax;
     const double aAh = ASYM ? 0.5 * sm->aA : 0.0, aB = ASYM ? sm->aB : 1.0, c2 = ASYM ? sm->c2 : 0.0;
+    double s[KG];
 #pragma unroll
-    for (int k = 0; k < KU; k++) {
-        double s = tm_mult_sum<NC>(x2[k], nu2, hq, g2);
+    for (int k = 0; k < KG; k++) {
+        s[k] = tm_mult_sum<NC>(x2[k], nu2, hq, g2);
         if (ASYM) {
             const double a = __builtin_fma(x2[k], aAh, aB);
-            s = s * __builtin_fma(a, a, c2);
+            s[k] = s[k] * __builtin_fma(a, a, c2);
         }
-        const bool inside = (bi[k] >= imin) && (bi[k] < imax);
-        acc[k] += inside ? s : 0.0;
+    }
+    if (edge) {
+        const int imin = sm->imin, imax = sm->imax;
+#pragma unroll
+        for (int k = 0; k < KG; k++) {
+            const bool inside = (bi[k] >= imin) && (bi[k] < imax);
+            s[k] = inside ? s[k] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KG; k++) acc[k] += s[k];
+}
+
+template <int KG>
+__device__ __forceinline__ void tm_accum_dispatch(TmMultK sm, const int shape, const double (&x2)[KG], const int (&bi)[KG], double (&acc)[KG], const bool edge)
+{
+    // shape = ncomp | has_asym << 8, from the active list (known before the record arrives)
+    switch (shape) {
+    case 1: tm_accum_mult<1, KG, false>(sm, x2, bi, acc, edge); break;
+    case 3: tm_accum_mult<3, KG, false>(sm, x2, bi, acc, edge); break;
+    case 5: tm_accum_mult<5, KG, false>(sm, x2, bi, acc, edge); break;
+    case 7: tm_accum_mult<7, KG, false>(sm, x2, bi, acc, edge); break;
+    case 256 + 1: tm_accum_mult<1, KG, true>(sm, x2, bi, acc, edge); break;
+    case 256 + 3: tm_accum_mult<3, KG, true>(sm, x2, bi, acc, edge); break;
+    case 256 + 5: tm_accum_mult<5, KG, true>(sm, x2, bi, acc, edge); break;
+    default: tm_accum_mult<7, KG, true>(sm, x2, bi, acc, edge); break;
     }
 }
 
-// Backward: accumulate this thread's partial sums for multiplet `sm` over all S sub-blocks, reduce over
-// the wave and leave the wave totals in s_red_row[slot].
+// Backward, one unit (2 bins per thread) of one multiplet: add this thread's terms to g[].
 //   g[3m+0] = sum wA r_m, g[3m+1] = sum wA d_m r_m^2, g[3m+2] = sum wA r_m^2   (d = 2x - 2nu, r = 1/E)
 //   g[3NC..3NC+2] = sum w S, sum w S a, sum w S a x   (S = un-asymmetrised multiplet sum; zero if asym == 0)
-template <int NC, int KU, bool ASYM>
+// edge (wave-uniform) = false: the unit lies inside the window and the grid (no test per bin).  Only the fetch of x and
+// of the weight differs between the two cases; the arithmetic exists once (two copies updating g[] behind a branch cost
+// ~40 registers in copies at the join).
+template <int NC, bool ASYM>
+__device__ __forceinline__ void tm_grad_unit(const double (&nu2)[NC], const double (&hq)[NC], double g2, double aAh, double aB, double c2,
+                                             int imin, int imax, const double *__restrict__ gx, const double *wq, int i0, int Nx,
+                                             const bool edge, double (&g)[TM_GSLOTS])
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        double x2, wk;
+        if (edge) {
+            const int i = i0 + k * TM_THREADS;
+            const bool inside = (i >= imin) && (i < imax) && (i < Nx);
+            x2 = 2.0 * gx[i < Nx ? i : Nx - 1];
+            wk = inside ? wq[k * TM_THREADS] : 0.0;
+        } else {
+            x2 = 2.0 * gx[i0 + k * TM_THREADS];
+            wk = wq[k * TM_THREADS];
+        }
+        double d[NC], r[NC];
+        const double Sv = tm_mult_value<NC>(x2, nu2, hq, g2, d, r);
+        double wA = wk;
+        if (ASYM) {
+            const double a = __builtin_fma(x2, aAh, aB);
+            wA = wk * __builtin_fma(a, a, c2);
+            const double ws = wk * Sv;
+            g[3 * NC + 0] += ws;
+            g[3 * NC + 1] = __builtin_fma(ws, a, g[3 * NC + 1]);
+            g[3 * NC + 2] = __builtin_fma(ws * a, 0.5 * x2, g[3 * NC + 2]);
+        }
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            const double t1 = wA * r[m];
+            const double t2 = t1 * r[m];
+            g[3 * m + 0] += t1;
+            g[3 * m + 1] = __builtin_fma(t2, d[m], g[3 * m + 1]);
+            g[3 * m + 2] += t2;
+        }
+    }
+}
+
+// Backward: accumulate this thread's partial sums for multiplet `sm` over the tile's units [u0, u1), reduce over the wave
+// and leave the wave totals in s_red_row[slot].
+template <int NC, bool ASYM>
 __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restrict__ gx, const double *s_w,
-                                             int base, int S, int Nx, int tid, int lane, double *s_red_row)
+                                             int u0, int u1, int Nx, int tid, int lane, double *s_red_row)
 {
     constexpr int V = ASYM ? 3 * NC + 3 : 3 * NC;
     double g[TM_GSLOTS];
@@ -247,36 +305,12 @@ __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restric
 #pragma unroll
     for (int s = 0; s < TM_GSLOTS; s++) g[s] = 0.0;
 #pragma unroll 1
-    for (int u = 0; u < S; u++) {
-        // skip sub-blocks that do not meet the window (wave-uniform: bounds of the whole sub-block)
-        const int lo = base + u * KU * TM_THREADS, hi = lo + KU * TM_THREADS;
+    for (int u = u0; u < u1; u++) {
+        // units that do not meet the window are skipped, units inside it need no test per bin (wave-uniform)
+        const int lo = u << TM_UNIT_SHIFT, hi = lo + TM_UNIT_BINS;
         if (hi <= imin || lo >= imax) continue;
-#pragma unroll
-        for (int k = 0; k < KU; k++) {
-            const int i = lo + k * TM_THREADS + tid;
-            const bool inside = (i >= imin) && (i < imax) && (i < Nx);
-            const double x2 = 2.0 * gx[i < Nx ? i : Nx - 1];
-            const double wk = inside ? s_w[(u * KU + k) * TM_THREADS + tid] : 0.0;
-            double d[NC], r[NC];
-            const double Sv = tm_mult_value<NC>(x2, nu2, hq, g2, d, r);
-            double wA = wk;
-            if (ASYM) {
-                const double a = __builtin_fma(x2, aAh, aB);
-                wA = wk * __builtin_fma(a, a, c2);
-                const double ws = wk * Sv;
-                g[3 * NC + 0] += ws;
-                g[3 * NC + 1] = __builtin_fma(ws, a, g[3 * NC + 1]);
-                g[3 * NC + 2] = __builtin_fma(ws * a, 0.5 * x2, g[3 * NC + 2]);
-            }
-#pragma unroll
-            for (int m = 0; m < NC; m++) {
-                const double t1 = wA * r[m];
-                const double t2 = t1 * r[m];
-                g[3 * m + 0] += t1;
-                g[3 * m + 1] = __builtin_fma(t2, d[m], g[3 * m + 1]);
-                g[3 * m + 2] += t2;
-            }
-        }
+        const double *wq = s_w + (u - u0) * TM_UNIT_BINS + tid;
+        tm_grad_unit<NC, ASYM>(nu2, hq, g2, aAh, aB, c2, imin, imax, gx, wq, lo + tid, Nx, !(lo >= imin && hi <= imax && hi <= Nx), g);
     }
 #if defined(TM_ABLATE) && (TM_ABLATE & 1)   // timing-only build: no wave reduction of the partials
     if (lane == 0) s_red_row[0] = g[0] + g[1] + g[2];
@@ -294,17 +328,11 @@ __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restric
     }
 }
 
-#ifndef TM_UG_FWD
-#define TM_UG_FWD 1     // sub-blocks per multiplet-loop group, likelihood kernel (KU = 4: already 4 chains per record fetch)
-#endif
-#ifndef TM_UG_GRAD
-#define TM_UG_GRAD 2    // gradient kernel (KU = 2): 4 bins per record fetch
-#endif
 #ifndef TM_LB_FWD
 #define TM_LB_FWD 4    // resident waves per SIMD the register allocator must allow (likelihood-only kernel)
 #endif
 #ifndef TM_LB_GRAD
-#define TM_LB_GRAD 3   // same for the gradient kernel: 155 VGPRs at KU=2 once the multiplet records live in SGPRs
+#define TM_LB_GRAD 4   // same for the gradient kernel: 128 VGPRs (the pair loop is written to fit: see tm_eval_body)
 #endif
 #ifdef TM_TRACE   // developer build: per-workgroup time stamps (tools/block_trace.py)
 __device__ unsigned long long *g_tm_trace = nullptr;
@@ -312,20 +340,26 @@ __device__ unsigned long long *g_tm_trace = nullptr;
 #else
 #define TM_STAMP(slot) do { } while (0)
 #endif
+
+template <int N> struct TmInt { static constexpr int value = N; };
+template <bool B> struct TmBool { static constexpr bool value = B; };
+
 // The workgroup's work for (chain, tile): pass 1 (model, likelihood partials, weights), in-launch finalize or pass 2.
-// s_w: dynamic LDS for the weights, [TM_THREADS * KU * S] doubles (GRAD only).  Called by tamcmc_eval_kernel
+// s_w: dynamic LDS for the weights, [TM_TILE_MAXU * TM_UNIT_BINS] doubles (GRAD only).  Called by tamcmc_eval_kernel
 // (tamcmc_eval.hip) and by the fused small-grid kernel (tamcmc_fused.hip).
-template <int KU, bool GRAD>
+//
+// The tile's units [u0, u1) (TmTileHdr, chosen per chain by the setup kernel) are walked in GROUPS of two units (four
+// bins per thread share one fetch of a multiplet's record and one window test; four independent rational chains are in
+// flight) -- a single unit where the tile ends on an odd unit or a group would straddle two cells.  A group that lies
+// inside the grid takes the FULL path: no index clamps, no per-bin validity tests, loads at constant offsets from one
+// per-thread pointer; within it a multiplet whose window covers the whole group takes the no-test form of
+// tm_accum_mult.  Only the grid's last, partial unit takes the guarded path.
+template <bool GRAD>
 __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chain, const int tile, double *s_w)
 {
     const int tid = threadIdx.x;
-    TmNoiseK sn = (TmNoiseK)(a.noise + chain);
-    const int u_first = TM_TILE_U0(tile, a.tile_big, a.tile_small);
-    const int S = TM_TILE_S(tile, a.tile_big, a.tile_small, a.units);   // sub-blocks of this tile
-    constexpr int KU2 = (KU > 2) ? 2 : KU;   // pass 2 keeps 3 accumulators per component: fewer bins in flight
-    const int Sp2 = S * (KU / KU2);          // sub-blocks of pass 2
     const int lane = tid & 63, wave = tid >> 6;
-    const int base = u_first * (TM_THREADS * KU);
+    TmNoiseK sn = (TmNoiseK)(a.noise + chain);
 
 #if defined(TM_ABLATE) && (TM_ABLATE & 16)   // timing-only build: empty workgroups (dispatch cost only)
     if (a.Nx > 0) return;
@@ -333,104 +367,104 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     __shared__ double s_red[2][TM_WAVES][TM_GSLOTS];   // double-buffered: one barrier per multiplet in pass 2
 
     // ---------------- prologue: nothing but scalar loads ----------------
-    // Everything a tile needs -- its list of active multiplets (table order), the background polynomial, the
-    // chain's noise record, the multiplet records themselves -- was prepared by the setup kernel and is
+    // Everything a tile needs -- its bounds, its list of active multiplets (table order), the cells' background
+    // polynomials, the chain's noise record, the multiplet records themselves -- was prepared by the setup kernel and is
     // wave-uniform: it is fetched with s_load into SGPRs.  No LDS staging, no barrier before the first bin.
-    // the chain's spectrum: contexts holding several spectra on one grid (ensembles, tamcmc_ctx_set_spectra) keep them as
-    // consecutive blocks of Nx
-    // (read through the constant address space: a scalar load, so that the two base pointers stay in SGPRs)
+    // The chain's spectrum: contexts holding several spectra on one grid (ensembles, tamcmc_ctx_set_spectra) keep them
+    // as consecutive blocks of Nx.
     const size_t spec_off = (a.spec != nullptr) ? (size_t)((TmIdxK)a.spec)[chain] * (size_t)a.Nx : 0;
     const double *__restrict__ yp = a.y + spec_off;
     const double *__restrict__ isp = a.isig2 + spec_off;      // dereferenced only when the likelihood is chi_square (then non-NULL)
     const TmMult *__restrict__ gm = a.mult + (size_t)chain * a.n_mult;
-    TmTileRecK tr = (TmTileRecK)(a.trec + (size_t)chain * a.tiles + tile);
-    TmIdxK tix = (TmIdxK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
+    TmTileHdrK th = (TmTileHdrK)(a.thdr + (size_t)chain * a.tiles + tile);
+    const int u0 = th->u0;
+    int u1 = th->u1;
+    if (u1 - u0 > TM_TILE_MAXU) u1 = u0 + TM_TILE_MAXU;      // the setup kernel never builds such a tile (and flags it if it did)
+    const int nact = th->nact;
+    TmCellRecK cells = (TmCellRecK)(a.cell + (size_t)chain * a.cells);
+    TmActiveK tix = (TmActiveK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
     const int nh = sn->nh;
-    const int nact = tr->nact;
-    const bool npoly = tr->npoly != 0;
-    const double lxc = tr->lxc;
     const bool has_gauss = sn->has_gauss != 0;
     const double N0 = sn->N0;
     const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
+    // FULL groups address the grid as (wave-uniform base pointer) + (32-bit per-thread bin index): global loads with a
+    // scalar base and one VGPR of offset, instead of one 64-bit pointer per array and thread (Nx < 2^28 is checked at create)
+    const double *__restrict__ xb = a.x;
+    const double *__restrict__ lb = a.lx;
 
 #if defined(TM_ABLATE) && (TM_ABLATE & 32)   // timing-only build: prologue (scalar loads) only
-    if (nact >= 0 && lxc == lxc && N0 == N0) { if (tid == 0 && !GRAD) a.part[((size_t)chain * a.tiles + tile) * 2] = (double)(nh + row + (npoly ? 1 : 0) + (has_gauss ? 1 : 0)); return; }
+    if (nact >= 0 && N0 == N0) { if (tid == 0 && !GRAD) a.part[((size_t)chain * a.tiles + tile) * 2] = (double)(nh + row + u0 + (has_gauss ? 1 : 0)); return; }
 #endif
     // ---------------- pass 1: model spectrum and likelihood partial sums ----------------
     double S1 = 0.0;
     double P = 1.0;
     int esum = 0;
-    double Mmin = 1.0;
+    int sgn = 0;                        // OR of the model values' high words: the sign bit tells whether any was negative
     double gn_[GRAD ? TM_GSLOTS : 1];   // GRAD: noise partial sums (3 per Harvey, sum w at slot 3*TM_MAXH, Gaussian at 13..15)
 #pragma unroll
     for (int s_ = 0; s_ < (GRAD ? TM_GSLOTS : 1); s_++) gn_[s_] = 0.0;
     const double wscale = GRAD ? a.wt[2 * chain + 1] : 0.0;
 
-    // The multiplet loop runs on UG sub-blocks at a time (UG * KU bins per thread): a multiplet's record is fetched
-    // (scalar loads) once per group, and UG * KU independent rational chains are in flight; background, likelihood
-    // and the gradient weights are then done sub-block by sub-block as before.
-    constexpr int UG = GRAD ? TM_UG_GRAD : TM_UG_FWD, KG = UG * KU;
-#pragma unroll 1
-    for (int ug = 0; ug < S; ug += UG) {
-        double x2g[KG], accg[KG];
-        int big[KG];
+    // one group of KG / 2 units starting at unit u, inside cell `tr`
+    auto group = [&](auto kg_c, auto full_c, const int u, TmCellRecK tr) __attribute__((always_inline)) {
+        constexpr int KG = decltype(kg_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
+        const int lo = u << TM_UNIT_SHIFT, hi = lo + KG * TM_THREADS;
+        double x2[KG], acc[KG];
+        int bi[KG];
 #pragma unroll
         for (int k = 0; k < KG; k++) {
-            const int i = base + (ug * KU + k) * TM_THREADS + tid;
-            const bool valid = (i < a.Nx) && (ug + k / KU < S);
-            big[k] = valid ? i : -1;
-            x2g[k] = 2.0 * a.x[(i < a.Nx) ? i : a.Nx - 1];
-            accg[k] = 0.0;
-        }
-        {
-            const int lo = base + ug * KU * TM_THREADS;
-            const int hi = lo + ((ug + UG <= S) ? KG : (S - ug) * KU) * TM_THREADS;
-            for (int jj = 0; jj < nact; jj++) {
-                TmMultK sm = (TmMultK)(gm + tix[jj]);
-                if (hi <= sm->imin || lo >= sm->imax) continue;   // wave-uniform skip
-                if (sm->has_asym) {
-                    switch (sm->ncomp) {
-                    case 1: tm_accum_mult<1, KG, true>(sm, x2g, big, accg); break;
-                    case 3: tm_accum_mult<3, KG, true>(sm, x2g, big, accg); break;
-                    case 5: tm_accum_mult<5, KG, true>(sm, x2g, big, accg); break;
-                    default: tm_accum_mult<7, KG, true>(sm, x2g, big, accg); break;
-                    }
-                } else {
-                    switch (sm->ncomp) {
-                    case 1: tm_accum_mult<1, KG, false>(sm, x2g, big, accg); break;
-                    case 3: tm_accum_mult<3, KG, false>(sm, x2g, big, accg); break;
-                    case 5: tm_accum_mult<5, KG, false>(sm, x2g, big, accg); break;
-                    default: tm_accum_mult<7, KG, false>(sm, x2g, big, accg); break;
-                    }
-                }
+            const int i = lo + k * TM_THREADS + tid;
+            if (FULL) {
+                bi[k] = i;
+                x2[k] = 2.0 * xb[(unsigned)i];
+            } else {
+                const bool valid = i < a.Nx;
+                bi[k] = valid ? i : -1;
+                x2[k] = 2.0 * a.x[valid ? i : a.Nx - 1];
             }
+            acc[k] = 0.0;
         }
+        // likelihood-only kernel (registers to spare): log x and y are requested now, so that their latency passes
+        // behind the multiplet loop instead of in front of the background / likelihood arithmetic
+        constexpr bool EARLY = FULL && !GRAD;
+        double lxe[EARLY ? KG : 1], ye[EARLY ? KG : 1];
+        if constexpr (EARLY) {
 #pragma unroll
-      for (int uu = 0; uu < UG; uu++) {
-        const int u = ug + uu;
-        if (u >= S) break;
-        double x2[KU], acc[KU], wreg[GRAD ? KU : 1];
-        int bi[KU];
+            for (int k = 0; k < KG; k++) { lxe[k] = (nh > 0) ? lb[(unsigned)bi[k]] : 0.0; ye[k] = yp[(unsigned)bi[k]]; }
+        }
+        for (int jj = 0; jj < nact; jj++) {
+            const int idx = tix[jj].idx, imin = tix[jj].imin, imax = tix[jj].imax, shape = tix[jj].shape;   // one 16-byte scalar load
+            if (hi <= imin || lo >= imax) continue;   // wave-uniform skip
+            tm_accum_dispatch<KG>((TmMultK)(gm + idx), shape, x2, bi, acc, !(FULL && lo >= imin && hi <= imax));
+        }
+        // background, likelihood and (GRAD) weights + noise partial sums, KH bins at a time: the gradient kernel keeps
+        // three accumulators per component in pass 2 and sixteen noise sums here, so it takes the four bins of a group
+        // in two halves (fewer values live at once: 4 waves per SIMD instead of 3)
+        constexpr int KH = GRAD ? 2 : KG;
+        const bool npoly = tr->npoly != 0;
 #pragma unroll
-        for (int k = 0; k < KU; k++) { x2[k] = x2g[uu * KU + k]; acc[k] = accg[uu * KU + k]; bi[k] = big[uu * KU + k]; }
-        double hu[TM_MAXH][GRAD ? KU : 1], harg[GRAD ? KU : 1];   // GRAD: u = 1/(1+t) per Harvey and bin (t u = 1 - u), log x per bin
+        for (int h0 = 0; h0 < KG; h0 += KH) {
+        double hu[TM_MAXH][GRAD ? KH : 1], harg[GRAD ? KH : 1];   // GRAD: u = 1/(1+t) per Harvey and bin (t u = 1 - u), log x per bin
         bool n0_done = false;
         if (nh > 0) {
-            double dl[KU];
+            double dl[KH];
 #pragma unroll
+            for (int k = 0; k < KH; k++) {
 #if defined(TM_ABLATE) && (TM_ABLATE & 128)   // timing-only build: no log x load (wrong values)
-            for (int k = 0; k < KU; k++) { dl[k] = lxc + 1e-9 * x2[k]; if constexpr (GRAD) harg[k] = dl[k]; }
+                dl[k] = tr->lxc + 1e-9 * x2[h0 + k];
 #else
-            for (int k = 0; k < KU; k++) { dl[k] = a.lx[bi[k] >= 0 ? bi[k] : a.Nx - 1]; if constexpr (GRAD) harg[k] = dl[k]; }
+                dl[k] = EARLY ? lxe[h0 + k] : FULL ? lb[(unsigned)bi[h0 + k]] : a.lx[bi[h0 + k] >= 0 ? bi[h0 + k] : a.Nx - 1];
 #endif
+                if constexpr (GRAD) harg[k] = dl[k];
+            }
             if (npoly) {
-#pragma unroll
-                for (int k = 0; k < KU; k++) dl[k] -= lxc;
+                const double lxc = tr->lxc;
                 // whole background (all profiles + white noise) as ONE polynomial: 8 FMAs per bin.  The gradient path
                 // accumulates the moments sum w dl^j instead of per-profile sums (below); the backward kernel turns
                 // them into the per-profile sums with each profile's own series coefficients.
 #pragma unroll
-                for (int k = 0; k < KU; k++) { acc[k] += tm_poly(tr, dl[k]); if constexpr (GRAD) harg[k] = dl[k]; }
+                for (int k = 0; k < KH; k++) { dl[k] -= lxc; acc[h0 + k] += tm_poly(tr, dl[k]); if constexpr (GRAD) harg[k] = dl[k]; }
                 n0_done = true;
             } else {
 #pragma unroll
@@ -438,10 +472,10 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                     if (h < nh) {
                         const double Hh = sn->H[h], ph = sn->p[h], lth = sn->lt[h];
 #pragma unroll
-                        for (int k = 0; k < KU; k++) {
+                        for (int k = 0; k < KH; k++) {
                             const double t = exp(ph * (lth + dl[k]));
                             const double uu = 1.0 / (t + 1.0);
-                            acc[k] += Hh * uu;
+                            acc[h0 + k] += Hh * uu;
                             if constexpr (GRAD) hu[h][k] = uu;
                         }
                     }
@@ -451,34 +485,34 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
         if (has_gauss) {
             const double gA = sn->gA, gnu0 = sn->gnu0, gs2 = sn->gs2;
 #pragma unroll
-            for (int k = 0; k < KU; k++) {
-                const double dd = 0.5 * x2[k] - gnu0;
-                acc[k] = gA * exp((-0.5 * (dd * dd)) / gs2) + acc[k];
+            for (int k = 0; k < KH; k++) {
+                const double dd = 0.5 * x2[h0 + k] - gnu0;
+                acc[h0 + k] = gA * exp((-0.5 * (dd * dd)) / gs2) + acc[h0 + k];
             }
         }
         if (!n0_done) {
 #pragma unroll
-            for (int k = 0; k < KU; k++) acc[k] += N0;
+            for (int k = 0; k < KH; k++) acc[h0 + k] += N0;
         }
-
         if (row >= 0) {
 #pragma unroll
-            for (int k = 0; k < KU; k++)
-                if (bi[k] >= 0) a.model_out[(size_t)row * a.Nx + bi[k]] = acc[k];
+            for (int k = 0; k < KH; k++)
+                if (FULL || bi[h0 + k] >= 0) a.model_out[(size_t)row * a.Nx + (size_t)(lo + (h0 + k) * TM_THREADS + tid)] = acc[h0 + k];
         }
 
+        double wreg[GRAD ? KH : 1];
         if (a.likelihood_case == 0) {
             // -p * (sum y/M + sum log M), likelihoods.cpp:23-25
 #pragma unroll
-            for (int k = 0; k < KU; k++) {
+            for (int k = 0; k < KH; k++) {
                 double wv = 0.0;
-                if (bi[k] >= 0) {
+                if (FULL || bi[h0 + k] >= 0) {
                     // A model value that is NaN, +-inf or 0 turns rM (and so S1) into NaN by itself (v_rcp_f64 + the
-                    // Newton steps); a negative one is caught by the running minimum.  Either way logL becomes NaN,
-                    // which is what log() of such a value gives the reference.
-                    const double M = acc[k];
-                    const double yv = yp[bi[k]];
-                    Mmin = __builtin_fmin(Mmin, M);
+                    // Newton steps); a negative one is caught by the sign bits collected in sgn.  Either way logL
+                    // becomes NaN, which is what log() of such a value gives the reference.
+                    const double M = acc[h0 + k];
+                    const double yv = EARLY ? ye[h0 + k] : FULL ? yp[(unsigned)bi[h0 + k]] : yp[bi[h0 + k]];
+                    sgn |= __double2hiint(M);
                     const double rM = tm_rcp(M);
                     S1 = __builtin_fma(yv, rM, S1);
                     int e;
@@ -486,7 +520,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                     esum += e;
                     wv = wscale * (yv * rM * rM - rM);   // d(logL/T)/dM_i
                 }
-                if constexpr (GRAD) { s_w[(u * KU + k) * TM_THREADS + tid] = wv; wreg[k] = wv; }
+                if constexpr (GRAD) wreg[k] = wv;
             }
             {
                 int e;
@@ -496,25 +530,28 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
         } else {
             // -sum (y-M)^2 / sigma^2, likelihoods.cpp:36
 #pragma unroll
-            for (int k = 0; k < KU; k++) {
+            for (int k = 0; k < KH; k++) {
                 double wv = 0.0;
-                if (bi[k] >= 0) {
-                    const double dd = yp[bi[k]] - acc[k];
-                    const double is2 = isp[bi[k]];
+                if (FULL || bi[h0 + k] >= 0) {
+                    const int i = lo + (h0 + k) * TM_THREADS + tid;
+                    const double dd = yp[i] - acc[h0 + k];
+                    const double is2 = isp[i];
                     S1 = __builtin_fma(dd * dd, is2, S1);
                     wv = wscale * dd * is2;
                 }
-                if constexpr (GRAD) { s_w[(u * KU + k) * TM_THREADS + tid] = wv; wreg[k] = wv; }
+                if constexpr (GRAD) wreg[k] = wv;
             }
         }
         if constexpr (GRAD) {
-            // noise partial sums, reusing u and t*u of this sub-block (no second pass over the bins)
+            // weights for pass 2 (each thread re-reads only its own entries) and the noise partial sums, reusing u and
+            // t*u of these bins (no second pass over the bins)
 #pragma unroll
-            for (int k = 0; k < KU; k++) {
+            for (int k = 0; k < KH; k++) {
                 const double wk = wreg[k];
+                s_w[((u - u0) * 2 + h0 + k) * TM_THREADS + tid] = wk;
                 gn_[3 * TM_MAXH] += wk;
                 if (nh > 0 && npoly) {
-                    // moments of the weights about the tile centre: slot j-1 <- sum w dl^j, j = 1..TM_HSER-1
+                    // moments of the weights about the cell centre: slot j-1 <- sum w dl^j, j = 1..TM_HSER-1
                     double q = wk;
 #pragma unroll
                     for (int j = 0; j < TM_HSER - 1; j++) { q *= harg[k]; gn_[j] += q; }
@@ -532,7 +569,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                 }
                 if (has_gauss) {
                     // Gaussian term: sum w e, sum w e d, sum w e d^2 with e = exp(-0.5 d^2/s2), d = x - nu0
-                    const double dd = 0.5 * x2[k] - sn->gnu0;
+                    const double dd = 0.5 * x2[h0 + k] - sn->gnu0;
                     const double we = wk * exp((-0.5 * (dd * dd)) / sn->gs2);
                     gn_[13] += we;
                     gn_[14] = __builtin_fma(we, dd, gn_[14]);
@@ -540,16 +577,68 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                 }
             }
         }
-      }   // sub-blocks of the group
+        if constexpr (GRAD) __builtin_amdgcn_sched_barrier(0);   // keep the halves apart: interleaved they need 40 more registers
+        }   // halves of the group
+    };
+
+    // GRAD: the noise partial sums of the cell just finished -> gnoise[chain][tile][part]
+    auto flush_noise = [&](const int part) __attribute__((always_inline)) {
+        if constexpr (GRAD) {
+            static_assert(TM_NSLOTS == 16, "butterfly below assumes 16 noise slots");
+            TmBfly<TM_NSLOTS, 32>::run(gn_, lane);
+            bool valid = true;
+            const int slot = TmBfly<TM_NSLOTS, 32>::slot_of(lane, valid);
+            double *red = s_red[1][wave];
+            if ((lane & 3) == 0) red[slot] = gn_[0];
+            __syncthreads();
+            if (tid < TM_NSLOTS) {
+                double t = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[1][wv][tid];
+                a.gnoise[(((size_t)chain * a.tiles + tile) * 2 + part) * TM_NSLOTS + tid] = t;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s_ = 0; s_ < TM_GSLOTS; s_++) gn_[s_] = 0.0;
+        }
+    };
+
+    {
+        // The walk over the tile's units.  The hot loop is the run of PAIRS (two units: four bins per thread), aligned
+        // to even units so that a pair never straddles two cells; it holds the only copy of the pair code, and nothing
+        // else updates the accumulators inside it (a second variant behind a branch in the same loop costs ~40
+        // registers in copies where the two meet).  An odd first unit is taken alone before the loop; what is left after
+        // it -- an odd last unit, and at the end of the grid the partial unit -- alone after it.
+        const int cell0 = u0 >> TM_CELL_SHIFT;
+        int cur_cell = cell0;
+        auto cell_of = [&](const int uu) __attribute__((always_inline)) {
+            const int ce = uu >> TM_CELL_SHIFT;
+            if (GRAD && ce != cur_cell) { flush_noise(0); cur_cell = ce; }   // at most once per tile (TM_TILE_MAXU <= TM_CELL_UNITS)
+            return cells + ce;
+        };
+        int u = u0;
+#if defined(TM_ABLATE) && (TM_ABLATE & 256)   // timing-only build: no pass 1
+        u = u1;
+#endif
+        if ((u & 1) && u < u1 && ((u + 1) << TM_UNIT_SHIFT) <= a.Nx) { TmCellRecK tr = cell_of(u); group(TmInt<2>(), TmBool<true>(), u, tr); u += 1; }
+#pragma unroll 1
+        for (; u + 2 <= u1 && ((u + 2) << TM_UNIT_SHIFT) <= a.Nx; u += 2) { TmCellRecK tr = cell_of(u); group(TmInt<4>(), TmBool<true>(), u, tr); }
+#pragma unroll 1
+        for (; u < u1; u += 1) {
+            TmCellRecK tr = cell_of(u);
+            if (((u + 1) << TM_UNIT_SHIFT) <= a.Nx) group(TmInt<2>(), TmBool<true>(), u, tr);
+            else                                    group(TmInt<2>(), TmBool<false>(), u, tr);
+        }
+        if (GRAD) flush_noise(cur_cell - cell0);
     }
     TM_STAMP(1);
     double S2 = 0.0;
 #if defined(TM_ABLATE) && (TM_ABLATE & 8)    // timing-only build: no log in the epilogue
-    S2 = P + (double)esum + Mmin;
+    S2 = P + (double)esum + (double)sgn;
 #else
     if (a.likelihood_case == 0) {
         S2 = log(P) + (double)esum * 0.693147180559945309417232;
-        if (!(Mmin > 0.0)) S2 = __builtin_nan("");
+        if (sgn < 0) S2 = __builtin_nan("");
     }
 #endif
     S1 = tm_wave_sum(S1);
@@ -568,9 +657,13 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     } else if (wave == 0) {
         // Finalize inside this launch: the workgroup that publishes the LAST tile partial of a chain sums all of them
         // in a fixed order (lane-strided, then a wave tree), so the result does not depend on which workgroup that is.
-        // Hand-off without cache-wide fences: the partials are written and read with agent-scope relaxed atomics
-        // (8-byte write-through stores / L1-bypassing loads), the publisher drains its stores (vmcnt(0)) before it
-        // takes its ticket, and the last arriver reads only after its ticket returned -- placement-independent.
+        // Hand-off without cache-wide fences: the partials are written and read with agent-scope relaxed atomics, which
+        // on gfx942 / gfx950 compile to global_store / global_load with sc1 (write-through to, and read from, the
+        // device-coherent level past the per-XCD L2s); the publisher drains its stores (s_waitcnt vmcnt(0)) before it
+        // takes its ticket (an agent-scope atomic add, executed at that same level), and the last arriver reads only
+        // after its ticket returned.  This is NOT the HIP memory model's release / acquire (no fence instructions: those
+        // cost 18 us per launch here); it relies on these gfx9 properties, and tests/test_parity_gpu.py
+        // (test_launch_order_does_not_change_results, run-to-run bitwise equality) is its guard.
         int last = 0;
         double *pp = a.part + (size_t)chain * a.tiles * 2;
         if (lane == 0) {
@@ -634,50 +727,29 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
 #endif
     // ---------------- pass 2: gradient partial sums ----------------
     if constexpr (GRAD) {
-        __syncthreads();   // s_red[0] (likelihood) consumed; s_w complete
-        // noise partial sums were accumulated in pass 1 (gn_): reduce and publish them
-        {
-            static_assert(TM_NSLOTS == 16, "butterfly below assumes 16 noise slots");
-            TmBfly<TM_NSLOTS, 32>::run(gn_, lane);
-            bool valid = true;
-            const int slot = TmBfly<TM_NSLOTS, 32>::slot_of(lane, valid);
-            double *red = s_red[1][wave];   // the buffer the last multiplet did not use
-            if ((lane & 3) == 0) red[slot] = gn_[0];
-        }
-        __syncthreads();
-        if (tid < TM_NSLOTS) {
-            double t = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[1][wv][tid];
-            a.gnoise[((size_t)chain * a.tiles + tile) * TM_NSLOTS + tid] = t;
-        }
-        __syncthreads();   // s_red[1] (noise) consumed before multiplet 0 reuses it
+        __syncthreads();   // s_red[0] (likelihood) consumed; s_w complete; s_red[1] (noise) consumed before multiplet 0 reuses it
 #if defined(TM_ABLATE) && (TM_ABLATE & 2)   // timing-only build: no multiplet pass 2 at all
         for (int jj = 0; jj < 0; jj++) {
 #else
         for (int jj = 0; jj < nact; jj++) {
 #endif
-            TmMultK sm = (TmMultK)(gm + tix[jj]);
-            const int nc = sm->ncomp;
+            const int idx = tix[jj].idx, shape = tix[jj].shape;
+            TmMultK sm = (TmMultK)(gm + idx);
+            const int nc = shape & 255;
             double *red = s_red[(jj + 1) & 1][wave];
-            if (sm->has_asym) {
-                switch (nc) {
-                case 1: tm_grad_mult<1, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                case 3: tm_grad_mult<3, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                case 5: tm_grad_mult<5, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                default: tm_grad_mult<7, KU2, true>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                }
-            } else {
-                if (lane == 0) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
-                switch (nc) {
-                case 1: tm_grad_mult<1, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                case 3: tm_grad_mult<3, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                case 5: tm_grad_mult<5, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                default: tm_grad_mult<7, KU2, false>(sm, a.x, s_w, base, Sp2, a.Nx, tid, lane, red); break;
-                }
+            if (shape < 256 && lane == 0) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
+            switch (shape) {
+            case 1: tm_grad_mult<1, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 3: tm_grad_mult<3, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 5: tm_grad_mult<5, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 7: tm_grad_mult<7, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 256 + 1: tm_grad_mult<1, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 256 + 3: tm_grad_mult<3, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 256 + 5: tm_grad_mult<5, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            default: tm_grad_mult<7, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
             }
 #if defined(TM_ABLATE) && (TM_ABLATE & 64)   // timing-only build: no workgroup barrier per multiplet (wave 0 publishes its own partial)
-            if (tid < TM_GSLOTS) a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + tix[jj]) * TM_GSLOTS + tid] = red[tid];
+            if (tid < TM_GSLOTS) a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + idx) * TM_GSLOTS + tid] = red[tid];
 #else
             __syncthreads();
             if (tid < TM_GSLOTS) {
@@ -686,7 +758,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
 #pragma unroll
                     for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[(jj + 1) & 1][wv][tid];
                 }
-                a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + tix[jj]) * TM_GSLOTS + tid] = t;
+                a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + idx) * TM_GSLOTS + tid] = t;
             }
 #endif
         }

@@ -23,46 +23,32 @@
 #include "tamcmc_setup_body.h"
 #include "tamcmc_eval_body.h"
 
-template <int KU, bool GRAD>
-__global__ __launch_bounds__(TM_THREADS) void tamcmc_fused_kernel(TmLayout L, TmFusedArgs f, TmEvalArgs a)
+template <bool GRAD>
+__global__ __launch_bounds__(TM_THREADS) void tamcmc_fused_kernel(TmLayout L, TmFusedArgs f, TmEvalArgs a, TmCostModel cm)
 {
-    extern __shared__ double s_dyn[];   // [f.p_doubles] this chain's params row, then [TM_THREADS * KU * S] weights (GRAD)
+    extern __shared__ double s_dyn[];   // [f.p_doubles] this chain's params row, then [TM_TILE_MAXU * TM_UNIT_BINS] weights (GRAD)
     const int chain = blockIdx.x;
-    tm_setup_body<TM_THREADS>(L, chain, f.params, f.Tcoefs, const_cast<double *>(a.wt), a.lx, TM_THREADS * KU, a.units, a.tile_big,
-                              a.tile_small, 1, const_cast<TmMult *>(a.mult), const_cast<TmNoise *>(a.noise),
-                              const_cast<TmTileRec *>(a.trec), const_cast<int32_t *>(a.tidx), static_cast<TmChain *>(f.chain_rec),
-                              static_cast<TmMultFull *>(f.aux), f.hser, nullptr, s_dyn);
+    const int units = (a.Nx + TM_UNIT_BINS - 1) >> TM_UNIT_SHIFT;
+    tm_setup_body<TM_THREADS>(L, chain, f.params, f.Tcoefs, const_cast<double *>(a.wt), a.lx, units, a.cells, 1, 0, cm,
+                              const_cast<TmMult *>(a.mult), const_cast<TmNoise *>(a.noise), const_cast<TmCellRec *>(a.cell),
+                              const_cast<TmTileHdr *>(a.thdr), const_cast<TmActive *>(a.tidx), static_cast<TmChain *>(f.chain_rec),
+                              static_cast<TmMultFull *>(f.aux), f.hser, nullptr, s_dyn, nullptr);
     __threadfence();
     __syncthreads();
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     TmEvalArgs b = a;
-    asm volatile("" : "+s"(b.mult), "+s"(b.noise), "+s"(b.trec), "+s"(b.tidx), "+s"(b.wt) : : "memory");
-    tm_eval_body<KU, GRAD>(b, chain, 0, s_dyn + f.p_doubles);
+    asm volatile("" : "+s"(b.mult), "+s"(b.noise), "+s"(b.cell), "+s"(b.thdr), "+s"(b.tidx), "+s"(b.wt) : : "memory");
+    tm_eval_body<GRAD>(b, chain, 0, s_dyn + f.p_doubles);
 }
 
-template <int KU>
-static int tm_launch_fused_k(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, bool grad, hipStream_t stream)
+int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, bool grad, void *stream_)
 {
-    const int Smax = a.tile_big > a.tile_small ? a.tile_big : a.tile_small;
-    const size_t lds = ((size_t)f.p_doubles + (grad ? (size_t)TM_THREADS * KU * Smax : 1)) * sizeof(double);
-    if (lds > 48 * 1024) {
-        const void *fn = grad ? reinterpret_cast<const void *>(tamcmc_fused_kernel<KU, true>)
-                              : reinterpret_cast<const void *>(tamcmc_fused_kernel<KU, false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (grad) hipLaunchKernelGGL((tamcmc_fused_kernel<KU, true>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a);
-    else      hipLaunchKernelGGL((tamcmc_fused_kernel<KU, false>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a);
+    if (a.n_mult > TM_MAXMULT || a.tiles != 1 || tm_units(a.Nx) > TM_TILE_MAXU) return (int)hipErrorInvalidValue;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int units = tm_units(a.Nx);
+    const size_t lds = ((size_t)f.p_doubles + (grad ? (size_t)units * TM_UNIT_BINS : 1)) * sizeof(double);
+    TmCostModel cm{0, 0, 0, 0};
+    if (grad) hipLaunchKernelGGL((tamcmc_fused_kernel<true>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a, cm);
+    else      hipLaunchKernelGGL((tamcmc_fused_kernel<false>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a, cm);
     return (int)hipGetLastError();
-}
-
-int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, int KU, bool grad, void *stream)
-{
-    if (a.n_mult > TM_MAXMULT || a.tiles != 1) return (int)hipErrorInvalidValue;
-    switch (KU) {
-    case 1: return tm_launch_fused_k<1>(L, f, a, Nchains, grad, (hipStream_t)stream);
-    case 2: return tm_launch_fused_k<2>(L, f, a, Nchains, grad, (hipStream_t)stream);
-    case 4: return tm_launch_fused_k<4>(L, f, a, Nchains, grad, (hipStream_t)stream);
-    default: return (int)hipErrorInvalidValue;
-    }
 }

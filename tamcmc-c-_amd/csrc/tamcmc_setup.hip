@@ -1,5 +1,5 @@
-// tamcmc_setup.hip -- per-chain prologue kernel: params row -> multiplet table, noise record, tile descriptors,
-// active-multiplet lists and launch ranks.  Compiled with -ffp-contract=off (see tamcmc_derive.h); the body lives in
+// tamcmc_setup.hip -- per-chain prologue kernel: params row -> multiplet table, noise record, cell polynomials,
+// equal-cost tile boundaries, active-multiplet lists and launch ranks.  Compiled with -ffp-contract=off (see tamcmc_derive.h); the body lives in
 // tamcmc_setup_body.h, which the fused small-grid kernel (tamcmc_fused.hip) shares.
 //
 // One workgroup of three waves per chain: one lane derives the chain's scalars, then wave 0 derives the multiplets,
@@ -10,26 +10,32 @@
 #include "tamcmc_dev.h"
 #include "tamcmc_setup_body.h"
 
-#define TM_SETUP_THREADS 192   // wave 0: multiplets; wave 1: noise record + tile polynomials; wave 2: m-ratios -- concurrently
+#define TM_SETUP_THREADS 192   // wave 0: multiplets; wave 1: noise record + cell polynomials; wave 2: m-ratios -- concurrently
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
                                                           const double *__restrict__ Tcoefs, double *__restrict__ wt,
-                                                          const double *__restrict__ lx, int UB, int units, int big, int small, int tiles,
+                                                          const double *__restrict__ lx, int units, int cells, int tiles, int equal_cost,
+                                                          TmCostModel cm, int p_doubles,
                                                           TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
-                                                          TmTileRec *__restrict__ trec, int32_t *__restrict__ tidx,
+                                                          TmCellRec *__restrict__ cell, TmTileHdr *__restrict__ thdr, TmActive *__restrict__ tidx,
                                                           TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
                                                           double *__restrict__ hser, int32_t *__restrict__ order)
 {
-    extern __shared__ double s_p[];   // this chain's params row: every later access is an LDS read
-    tm_setup_body<TM_SETUP_THREADS>(L, (int)blockIdx.x, params, Tcoefs, wt, lx, UB, units, big, small, tiles, mult, noise, trec, tidx,
-                                    chain_rec, aux, hser, order, s_p);
+    extern __shared__ double s_p[];   // this chain's params row (every later access is an LDS read), then the unit-cost prefix
+    int *s_pre = (equal_cost != 0) ? reinterpret_cast<int *>(s_p + p_doubles) : nullptr;
+    tm_setup_body<TM_SETUP_THREADS>(L, (int)blockIdx.x, params, Tcoefs, wt, lx, units, cells, tiles, equal_cost, cm, mult, noise, cell, thdr,
+                                    tidx, chain_rec, aux, hser, order, s_p, s_pre);
 }
 
-int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx, int unit_bins,
-                    int units, int big, int small, TmMult *d_mult, TmNoise *d_noise, TmTileRec *d_trec, int32_t *d_tidx,
-                    void *d_chain_rec, void *d_aux, double *d_hser, int32_t *d_order, void *stream)
+int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, const double *d_Tcoefs, double *d_wt, const double *d_lx,
+                    int units, int cells, int tiles, int equal_cost, TmCostModel cm, TmMult *d_mult, TmNoise *d_noise, TmCellRec *d_cell,
+                    TmTileHdr *d_thdr, TmActive *d_tidx, void *d_chain_rec, void *d_aux, double *d_hser, int32_t *d_order, void *stream)
 {
-    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), (size_t)L.Nparams * sizeof(double), (hipStream_t)stream, L,
-                       d_params, d_Tcoefs, d_wt, d_lx, unit_bins, units, big, small, tm_tile_count(units, big, small), d_mult, d_noise, d_trec, d_tidx,
+    if (tiles < 1 || (long long)tiles * TM_TILE_MAXU < units) return (int)hipErrorInvalidValue;
+    const int p_doubles = (L.Nparams + 1) & ~1;
+    const int eq = (equal_cost != 0 && tiles > 1 && tiles <= TM_ORDER_MAX && units <= TM_EQ_MAXU) ? 1 : 0;
+    const size_t lds = (size_t)p_doubles * sizeof(double) + (eq ? (size_t)units * sizeof(int) : 0);
+    hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), lds, (hipStream_t)stream, L,
+                       d_params, d_Tcoefs, d_wt, d_lx, units, cells, tiles, eq, cm, p_doubles, d_mult, d_noise, d_cell, d_thdr, d_tidx,
                        static_cast<TmChain *>(d_chain_rec), static_cast<TmMultFull *>(d_aux), d_hser, d_order);
     return (int)hipGetLastError();
 }

@@ -15,11 +15,12 @@
 template <int NT>
 __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain, const double *__restrict__ params,
                                               const double *__restrict__ Tcoefs, double *__restrict__ wt,
-                                              const double *__restrict__ lx, int UB, int units, int big, int small, int tiles,
-                                              TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
-                                              TmTileRec *__restrict__ trec, int32_t *__restrict__ tidx,
+                                              const double *__restrict__ lx, int units, int cells, int tiles, int equal_cost,
+                                              const TmCostModel cm, TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
+                                              TmCellRec *__restrict__ cell, TmTileHdr *__restrict__ thdr, TmActive *__restrict__ tidx,
                                               TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
-                                              double *__restrict__ hser, int32_t *__restrict__ order, double *p)
+                                              double *__restrict__ hser, int32_t *__restrict__ order, double *p,
+                                              int *s_pre /* LDS, [units] when tiles > 1 and units <= TM_EQ_MAXU, else unused */)
 {
     __shared__ int s_win[TM_MAXMULT][3];   // truncation windows and component counts, for the per-tile active lists
     __shared__ __attribute__((aligned(16))) int s_cost[TM_ORDER_MAX + 4];
@@ -78,21 +79,22 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         N.N0 = (take_abs ? fabs(n0) : n0) + extra;
     }
     if (tid >= 64 && tid < 128) {
-        // Wave 1, concurrently with wave 0's multiplet derivation: the Harvey background of every tile as Taylor
+        // Wave 1, concurrently with wave 0's multiplet derivation: the Harvey background of every cell as Taylor
         // polynomials in z = p (log x - log x_c).  u(z) = 1/(1 + t0 e^z) is analytic for |z| < pi (nearest pole at
         // ln(1/t0) + i pi), so for |z| <= 0.04 the series truncated at degree 8 is exact to (0.04/pi)^9 ~ 1e-17.
         // Coefficients by the power-series reciprocal of D(z) = 1 + t0 sum z^j/j!.
         // s_N was written by lane 0 of THIS wave: LDS operations of one wave complete in order.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 1)   // timing-only build: no tile polynomials
-        for (int tile = tiles; tile < tiles; tile += 64) {
+#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 1)   // timing-only build: no cell polynomials
+        for (int ce = cells; ce < cells; ce += 64) {
 #else
-        for (int tile = tid - 64; tile < tiles; tile += 64) {
+        for (int ce = tid - 64; ce < cells; ce += 64) {
 #endif
-            const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
-            TmTileRec R;
-            R.nact = 0;
+            const int base = ce * (TM_CELL_UNITS * TM_UNIT_BINS);
+            int TB = TM_CELL_UNITS * TM_UNIT_BINS; if (base + TB > L.Nx) TB = L.Nx - base;
+            TmCellRec R;
+            R.pad = 0;
             int ic = base + TB / 2; if (ic > L.Nx - 1) ic = L.Nx - 1;
             int i1 = base + TB - 1; if (i1 > L.Nx - 1) i1 = L.Nx - 1;
             const double lx_c = lx[ic], lx_0 = lx[base], lx_1 = lx[i1];
@@ -127,7 +129,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
                         u[j] = -id0 * acc;
                     }
                     double pj = 1.0;
-                    double *hs = (hser != nullptr) ? hser + (((size_t)chain * tiles + tile) * TM_MAXH + h) * TM_HSER : nullptr;
+                    double *hs = (hser != nullptr) ? hser + (((size_t)chain * cells + ce) * TM_MAXH + h) * TM_HSER : nullptr;
 #pragma unroll
                     for (int j = 0; j < TM_HSER; j++) {
                         const double cj = u[j] * pj;                 // coefficient of (log x - lxc)^j in u_h
@@ -138,7 +140,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
                 }
             }
             R.npoly = ok ? 1 : 0;
-            trec[(size_t)chain * tiles + tile] = R;    // nact is filled in below, once the windows are known
+            cell[(size_t)chain * cells + ce] = R;
         }
     }
 
@@ -193,20 +195,68 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         noise[chain] = s_N;
     }
 
-    // ---------------- active multiplet lists: one thread per tile ----------------
-    // the multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel)
+    // ---------------- tiles: per-chain boundaries, active multiplet lists, launch ranks ----------------
+    __shared__ int s_b[TM_ORDER_MAX + 2];      // tile boundaries in units (tiles <= TM_ORDER_MAX; else computed on the fly)
+    __shared__ int s_tot[2];                   // total cost, cheapest unit
     const int nm = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
+    const bool eq = (equal_cost != 0) && tiles > 1 && tiles <= TM_ORDER_MAX && units <= TM_EQ_MAXU && s_pre != nullptr;
+    const int su = (units + tiles - 1) / tiles;       // uniform tiles: su units each (su <= TM_TILE_MAXU by the tile count)
+    if (eq) {
+        // Equal-cost tiles.  (1) cost of every unit from the windows; (2) inclusive prefix sum (one wave: each lane a
+        // contiguous chunk, then a wave scan); (3) every boundary by a binary search in the prefix (tm_tile_bound,
+        // tamcmc_dev.h: integer arithmetic, tiles of at most TM_TILE_MAXU units guaranteed).
+        for (int u = tid; u < units; u += NT) {
+            const int lo = u << TM_UNIT_SHIFT, hi = lo + TM_UNIT_BINS;
+            int c = cm.c0;
+            for (int j = 0; j < nm; j++)
+                if (s_win[j][0] < hi && s_win[j][1] > lo) c += cm.a * s_win[j][2] + cm.b;
+            s_pre[u] = c;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int ch = (units + 63) >> 6;
+            const int lo = tid * ch, hi = (lo + ch < units) ? lo + ch : units;
+            int sum = 0, mn = 0x7fffffff;
+            for (int u = lo; u < hi; u++) { const int c = s_pre[u]; sum += c; mn = c < mn ? c : mn; }
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (tid >= off) incl += t; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mn, off, 64); mn = t < mn ? t : mn; }
+            int run = incl - sum;
+            for (int u = lo; u < hi; u++) { run += s_pre[u]; s_pre[u] = run; }
+            if (tid == 63) { s_tot[0] = incl; s_tot[1] = mn; }
+        }
+        __syncthreads();
+        const long long C = s_tot[0], cmin = s_tot[1];
+        for (int t = tid; t <= tiles; t += NT) {
+            const int b = (t == 0) ? 0 : (t == tiles) ? units : tm_tile_bound(t, tiles, units, s_pre, C, cmin);
+            s_b[t] = b;
+        }
+        __syncthreads();
+    }
+    // the multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel)
     for (int tile = tid; tile < tiles; tile += NT) {
-        const int base = TM_TILE_U0(tile, big, small) * UB, TB = TM_TILE_S(tile, big, small, units) * UB;
-        int32_t *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
+        int u0, u1;
+        if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
+        else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
+        if (u1 - u0 > TM_TILE_MAXU) { u1 = u0 + TM_TILE_MAXU; atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
+        const int base = u0 << TM_UNIT_SHIFT, end = u1 << TM_UNIT_SHIFT;
+        TmActive *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
         int nact = 0, cost = 0;
-        for (int j = 0; j < nm; j++)
-            if (s_win[j][0] < base + TB && s_win[j][1] > base) {
-                ti[nact++] = j;
-                const int lo = s_win[j][0] > base ? s_win[j][0] : base, hi = s_win[j][1] < base + TB ? s_win[j][1] : base + TB;
-                cost += (s_win[j][2] + 2) * ((hi - lo + 255) >> 8);     // ~ component evaluations, in units of 256 bins
-            }
-        trec[(size_t)chain * tiles + tile].nact = nact;
+        if (u1 > u0)
+            for (int j = 0; j < nm; j++)
+                if (s_win[j][0] < end && s_win[j][1] > base) {
+                    TmActive A;
+                    A.idx = j; A.imin = s_win[j][0]; A.imax = s_win[j][1]; A.shape = s_win[j][2] | (C.asym != 0 ? 256 : 0);
+                    ti[nact++] = A;
+                    const int lo = s_win[j][0] > base ? s_win[j][0] : base, hi = s_win[j][1] < end ? s_win[j][1] : end;
+                    cost += (cm.a * s_win[j][2] + cm.b) * ((hi - lo + 255) >> 8);     // ~ instructions, in units of 256 bins
+                }
+        cost += cm.c0 * 2 * (u1 - u0);
+        TmTileHdr H;
+        H.u0 = u0; H.u1 = u1; H.nact = nact; H.cost = cost;
+        thdr[(size_t)chain * tiles + tile] = H;
         // unique key: cost first, lower tile index first among equals
         if (tile < TM_ORDER_MAX) s_cost[tile] = ((cost < (1 << 20) ? cost : (1 << 20)) << 10) + (TM_ORDER_MAX - 1 - tile);
     }
@@ -232,6 +282,9 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
             for (int tile = tid; tile < tiles; tile += NT) order[(size_t)chain * tiles + tile] = tile;
         }
     }
+    // a tile that had to be clamped (never expected) is reported through the chain status
+    __syncthreads();
+    if (tid == 64 && s_status != s_N.status) noise[chain].status = s_status;
 }
 #pragma clang fp contract(fast)
 

@@ -87,7 +87,8 @@ def test_synthetic_generator_is_deterministic(accel_mod):
 
 
 def test_tile_geometry_partitions_the_grid():
-    """TM_TILE_U0 / TM_TILE_S / tm_tile_count (two alternating tile sizes): every sub-block belongs to exactly one tile."""
+    """tm_tiles / tm_tile_bound (tamcmc_dev.h; the setup kernel runs the same function): equal-cost boundaries cover the
+    grid in order with tiles of at most TM_TILE_MAXU units, whatever the unit costs."""
     import subprocess
     cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
     subprocess.run(["make", "-C", cpp, "-s", "geometry_check"], check=True)

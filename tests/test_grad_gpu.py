@@ -70,10 +70,13 @@ def test_gradient_full_size_is_reproducible(accel_mod, orc):
         L1, _, g1 = acc.eval_batch(P, T, grad=True)
         L2, _, g2 = acc.eval_batch(P, T, grad=True)
         L0, _, g0 = acc.eval_batch(P, np.ones(8), grad=True)
+        L3, _, g3 = acc.eval_batch(P, T, grad=True)
     assert np.array_equal(g1, g2) and np.array_equal(L1, L2)
+    assert np.array_equal(g1, g3) and np.array_equal(L1, L3)        # nothing of the launch in between is left behind
     assert np.all(np.isfinite(g1))
-    # tempering scales the gradient like the likelihood: g(T) * T == g(T = 1)  (model_def.cpp:302)
-    assert np.allclose(g1 * T[:, None], g0, rtol=1e-13, atol=0)
+    # tempering scales the gradient like the likelihood: g(T) * T == g(T = 1)  (model_def.cpp:302); entries are sums
+    # with cancellation, so the comparison is relative to the largest entry of the row
+    assert np.max(np.abs(g1 * T[:, None] - g0) / np.max(np.abs(g0), axis=1, keepdims=True)) <= 1e-12
     assert np.allclose(L1 * T, L0, rtol=1e-13, atol=0)
 
 

@@ -19,8 +19,8 @@ def test_eval_kernel_register_budget():
     usage = {}
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?VGPRs Spill: (\d+)", txt, flags=re.S):
         usage[m.group(1)] = (int(m.group(2)), int(m.group(4)), int(m.group(3)))       # VGPRs, spilled VGPRs, scratch bytes
-    grad = [v for k, v in usage.items() if "tamcmc_eval_kernelILi2ELb1" in k]
-    fwd = [v for k, v in usage.items() if "tamcmc_eval_kernelILi4ELb0" in k]
+    grad = [v for k, v in usage.items() if "tamcmc_eval_kernelILb1" in k]
+    fwd = [v for k, v in usage.items() if "tamcmc_eval_kernelILb0" in k]
     assert grad and fwd, txt[-2000:]
     assert grad[0][0] <= 128 and grad[0][1] == 0 and grad[0][2] == 0, grad
     assert fwd[0][0] <= 64 and fwd[0][1] == 0 and fwd[0][2] == 0, fwd

@@ -253,7 +253,8 @@ def test_large_grid_and_many_chains(accel_mod, orc):
 def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     """The eval launch is tile-major and costliest-first (rank table from the setup kernel).  Results must be bitwise
     the same for the chain-major order (TAMCMC_ORDER=0), plain tile-major (1) and ranked (2, default), and for a tile
-    count above TM_ORDER_MAX = 1024, where the rank table is the identity; and for tiles of two alternating sizes."""
+    count above TM_ORDER_MAX = 1024, where the rank table is the identity and tiles have equal length; and for other
+    tile counts, cost models of the balancer and equal-length tiles (agreement to rounding)."""
     w = synth.workload_c2(Nx=30000)
     y = spectrum_for(orc, w)
     P = synth.chain_params(w, 5)
@@ -271,15 +272,17 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
     check_logL(res[2][0], rL)
     monkeypatch.delenv("TAMCMC_ORDER")
-    # two tile sizes: other partial sums, same answer to rounding; gradient against the uniform geometry
-    for env in (dict(TAMCMC_S="4", TAMCMC_S2="1", TAMCMC_S_GRAD="9", TAMCMC_S2_GRAD="2"),
-                dict(TAMCMC_S="2", TAMCMC_S2="2", TAMCMC_S_GRAD="5", TAMCMC_S2_GRAD="4")):
+    # other tile boundaries (equal length instead of equal cost; other tile counts): other partial sums, same answer to
+    # rounding; gradient against the default geometry
+    for env in (dict(TAMCMC_EQUAL_COST="0"), dict(TAMCMC_TILES="9", TAMCMC_TILES_GRAD="11"),
+                dict(TAMCMC_TILES="40", TAMCMC_TILES_GRAD="59", TAMCMC_COST="10,1,1", TAMCMC_COST_GRAD="500,40,3")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
             acc.set_vars(w["index_to_relax"])
             L, st = acc.eval_batch(P, T)
             Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        assert np.all(st == 0) and np.all(stg == 0)
         check_logL(L, rL)
         check_logL(Lg, rL)
         assert np.max(np.abs(g - res[2][2]) / np.max(np.abs(res[2][2]), axis=1, keepdims=True)) < 1e-11
@@ -291,11 +294,11 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     y = spectrum_for(orc, w)
     P = synth.chain_params(w, 2)
     T = synth.temperatures(2)
-    monkeypatch.setenv("TAMCMC_S", "1")          # 1024-bin likelihood tiles, 1024-bin gradient tiles: 1172 of each
-    monkeypatch.setenv("TAMCMC_S_GRAD", "2")
+    monkeypatch.setenv("TAMCMC_TILES", "1200")          # more tiles than TM_ORDER_MAX: equal-length tiles, launched in tile order
+    monkeypatch.setenv("TAMCMC_TILES_GRAD", "1300")
     with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
         acc.set_vars(w["index_to_relax"])
-        assert acc.geometry()["tiles"] == 1172
+        assert acc.geometry()["tiles"] == 1200
         L, st = acc.eval_batch(P, T)
         Lg, stg, g = acc.eval_batch(P, T, grad=True)
     rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
@@ -303,6 +306,32 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     check_logL(L, rL)
     check_logL(Lg, rL)
     assert np.all(np.isfinite(g))
+
+
+def test_equal_cost_tiles_follow_the_chain_not_the_batch(accel_mod, orc):
+    """Tile boundaries are chosen per chain from that chain's own truncation windows (tamcmc_setup_body.h): chains with
+    very different window patterns in one batch -- narrow windows (most of the grid is background only), the default,
+    and windows that span the whole grid -- each give bit for bit what they give evaluated alone, and all agree with
+    the oracle."""
+    w = synth.workload_c2(Nx=60000)
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 9)
+    T = synth.temperatures(9)
+    q = W.split(w)["cfg"]
+    P[0:3, q] = 1.5        # trunc_c: windows of a few hundred bins
+    P[6:9, q] = 10000.0    # no truncation
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        L, st = acc.eval_batch(P, T)
+        Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        for k in (0, 4, 8):
+            L1, st1 = acc.eval_batch(P[k:k + 1], T[k:k + 1])
+            Lg1, _, g1 = acc.eval_batch(P[k:k + 1], T[k:k + 1], grad=True)
+            assert L1[0] == L[k] and Lg1[0] == Lg[k] and np.array_equal(g1[0], g[k])
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st, rst) and np.array_equal(stg, rst)
+    check_logL(L, rL)
+    check_logL(Lg, rL)
 
 
 def test_more_than_64_multiplets(accel_mod, orc):
