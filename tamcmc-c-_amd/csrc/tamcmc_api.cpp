@@ -38,7 +38,7 @@ struct tamcmc_ctx {
     int tiles_max = 1;
     int equal_cost = 0;            // TAMCMC_EQUAL_COST=1: per-chain tile boundaries of equal cost instead of equal length
     int prio = 0;                  // TAMCMC_PRIO=1: issue priority by launch rank (s_setprio)
-    TmCostModel cost_l{60, 5, 9, 0}, cost_g{110, 13, 24, 0};   // VALU instructions per bin: c0 + sum(a * ncomp + b) (TAMCMC_COST / TAMCMC_COST_GRAD)
+    TmCostModel cost_l{60, 5, 9, TM_TILE_MAXU_L}, cost_g{110, 13, 24, TM_TILE_MAXU};   // (.pad = units per tile at most)   // VALU instructions per bin: c0 + sum(a * ncomp + b) (TAMCMC_COST / TAMCMC_COST_GRAD)
     int last_tiles = 0;            // T of the most recent likelihood-only call (tamcmc_ctx_geometry)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -195,7 +195,7 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     TM_HIP(hipMalloc(&c->d_params, n * c->L.Nparams * sizeof(double)));
     TM_HIP(hipMalloc(&c->d_T, n * sizeof(double)));
     TM_HIP(hipMalloc(&c->d_logL, n * sizeof(double)));
-    TM_HIP(hipMalloc(&c->d_part, n * c->tiles_max * 2 * sizeof(double)));
+    TM_HIP(hipMalloc(&c->d_part, n * c->tiles_max * 4 * sizeof(double)));
     TM_HIP(hipMalloc(&c->d_status, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_rows, n * sizeof(int32_t)));
     TM_HIP(hipMalloc(&c->d_mult, n * nm * sizeof(TmMult)));
@@ -256,6 +256,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_FUSED", 0, 1, &c->fuse);
     env_int("TAMCMC_EQUAL_COST", 0, 1, &c->equal_cost);
     env_int("TAMCMC_PRIO", 0, 1, &c->prio);
+    env_int("TAMCMC_PRIO", 0, 1, &c->prio);
     auto env_cost = [](const char *name, TmCostModel *m) {
         const char *e = getenv(name);
         int c0, a, b;
@@ -269,11 +270,14 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
         c->tiles_l = tm_tiles(c->units, 0);
         c->tiles_g = tm_tiles(c->units, 1);
         // a tile count given by hand must still keep every tile within TM_TILE_MAXU units
-        const int tmin = (c->units + TM_TILE_MAXU - 1) / TM_TILE_MAXU + (c->units > TM_TILE_MAXU ? 1 : 0);
+        const int tmin_g = (c->units + TM_TILE_MAXU - 1) / TM_TILE_MAXU + (c->units > TM_TILE_MAXU ? 1 : 0);
+        const int tmin_l = (c->units + TM_TILE_MAXU_L - 1) / TM_TILE_MAXU_L + (c->units > TM_TILE_MAXU_L ? 1 : 0);
         if (c->units > 4) {
-            env_int("TAMCMC_TILES", tmin, 1 << 20, &c->tiles_l);
-            env_int("TAMCMC_TILES_GRAD", tmin, 1 << 20, &c->tiles_g);
+            env_int("TAMCMC_TILES", tmin_l, 1 << 20, &c->tiles_l);
+            env_int("TAMCMC_TILES_GRAD", tmin_g, 1 << 20, &c->tiles_g);
         }
+        // the balancer's guarantee is TM_TILE_MAXU units per tile; equal-length likelihood tiles may be longer
+        c->cost_l.pad = (c->equal_cost && (long long)c->tiles_l * TM_TILE_MAXU > c->units) ? TM_TILE_MAXU : TM_TILE_MAXU_L;
     }
     c->tiles_max = c->tiles_l > c->tiles_g ? c->tiles_l : c->tiles_g;
 
@@ -495,7 +499,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.cells = cells; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
-    a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio;
+    a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio; a.prio = c->prio;
     if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     // one tile per chain (short grids): prologue and evaluation share a launch

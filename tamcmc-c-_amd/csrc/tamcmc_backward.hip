@@ -161,9 +161,12 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     // finalize (same arithmetic and order as the likelihood-only path's in-launch finalize): wave 3
     if (tid >= 192) {
         const int lane = tid - 192;
-        const double *pp = part + (size_t)chain * tiles * 2;
+        const double *pp = part + (size_t)chain * tiles * 4;      // per tile: {S1, mantissa product, exponent sum, -}
         double s1 = 0.0, s2 = 0.0;
-        for (int t = lane; t < tiles; t += 64) { s1 += pp[2 * t]; s2 += pp[2 * t + 1]; }
+        for (int t = lane; t < tiles; t += 64) {
+            s1 += pp[4 * t];
+            if (L.likelihood_case == 0) s2 += log(pp[4 * t + 1]) + pp[4 * t + 2] * 0.693147180559945309417232;
+        }
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
         if (lane == 0) {
             double f = (L.likelihood_case == 0) ? -L.like_p * (s1 + s2) : -s1;

@@ -7,7 +7,7 @@
 //   noise[Nchains]          : TmNoise -- Harvey / white-noise / Gaussian terms per chain
 //   cell[Nchains][cells]    : TmCellRec -- background polynomial per fixed 4096-bin cell
 //   thdr[Nchains][tiles]    : TmTileHdr -- per-chain tile boundaries (equal-cost tiles), active-multiplet counts
-//   part[Nchains][tiles][2] : per-tile partial sums of the likelihood (fixed-order reduction)
+//   part[Nchains][tiles][4] : per-tile partial sums of the likelihood (fixed-order reduction)
 //   gmult[Nchains][tiles][n_mult][TM_GSLOTS], gnoise[Nchains][tiles][2][TM_NSLOTS] : gradient partials
 //   hser[Nchains][cells][TM_MAXH][TM_HSER] : per-profile series of u = 1/(1+t) in (log x - lxc), gradient path only
 //   logL[Nchains], status[Nchains] (int32), grad[Nchains][Nvars]
@@ -89,7 +89,8 @@ static_assert(sizeof(TmNoise) == 120, "TmNoise layout");
 #define TM_UNIT_SHIFT 9
 #define TM_CELL_UNITS 8
 #define TM_CELL_SHIFT 3
-#define TM_TILE_MAXU 8      // units per tile at most: 32 KB of gradient weights in LDS; a tile meets at most 2 cells
+#define TM_TILE_MAXU 8      // units per gradient tile at most: 32 KB of weights in LDS; a tile meets at most 2 cells
+#define TM_TILE_MAXU_L 16   // units per likelihood-only tile at most (no weights to keep)
 #define TM_EQ_MAXU 4096     // grids of up to this many units (2M bins) get equal-cost tiles (cost prefix lives in LDS)
 
 // Per (chain, cell) record written by the setup kernel and read by the eval kernel through scalar loads.
@@ -133,7 +134,7 @@ struct TmEvalArgs {
     const TmActive *tidx;       // [Nchains][tiles][n_mult] active multiplets, table order
     const int32_t *spec;        // NULL, or [Nchains]: which of the context's spectra (y, 1/sigma^2 blocks of Nx) a chain is fitted to
     const double *wt;           // [Nchains][2] {Tcoefs[chain], p/T or 2/T} copied by the setup kernel into device memory
-    double *part;               // [Nchains][tiles][2]
+    double *part;               // [Nchains][tiles][4]: sum y/M, sum log M as (mantissa product, exponent sum), pad
     double *gmult;              // [Nchains][tiles][n_mult][TM_GSLOTS] or NULL
     double *gnoise;             // [Nchains][tiles][2][TM_NSLOTS] or NULL: one set per cell the tile meets (at most 2)
     int32_t *ticket;            // [Nchains] arrival counters (zero between launches) for the in-launch finalize, or NULL

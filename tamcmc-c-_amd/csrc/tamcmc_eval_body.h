@@ -97,6 +97,24 @@ __device__ __forceinline__ double tm_wave_sum(double v)   // lane 0 ends with th
     return v;
 }
 
+__device__ __forceinline__ double tm_wave_prod(double v)   // product over the 64 lanes (every lane ends with it)
+{
+    const int lane = threadIdx.x & 63;
+    v *= tm_xor<32>(v, lane);
+    v *= tm_xor<16>(v, lane);
+    v *= tm_xor<8>(v, lane);
+    v *= tm_xor<4>(v, lane);
+    v *= tm_xor<2>(v, lane);
+    v *= tm_xor<1>(v, lane);
+    return v;
+}
+
+// sum of log M over a tile, kept as (mantissa product, exponent sum): sum log M = log(mant) + e ln 2.  The product of the
+// 64 lanes' running mantissas (each in [0.5, 1): at least 2^-64, no underflow) and then of the 4 waves' replaces a log per
+// thread; the logs are taken once per tile by whoever sums the tiles (tm_tile_logsum).
+#define TM_LN2 0.693147180559945309417232
+__device__ __forceinline__ double tm_tile_logsum(double mant, double e) { return log(mant) + e * TM_LN2; }
+
 // Horner evaluation of the cell's background polynomial; the coefficients are SGPR operands (scalar loads)
 __device__ __forceinline__ double tm_poly(TmCellRecK tr, double z)
 {
@@ -379,7 +397,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     TmTileHdrK th = (TmTileHdrK)(a.thdr + (size_t)chain * a.tiles + tile);
     const int u0 = th->u0;
     int u1 = th->u1;
-    if (u1 - u0 > TM_TILE_MAXU) u1 = u0 + TM_TILE_MAXU;      // the setup kernel never builds such a tile (and flags it if it did)
+    if (u1 - u0 > (GRAD ? TM_TILE_MAXU : TM_TILE_MAXU_L)) u1 = u0 + (GRAD ? TM_TILE_MAXU : TM_TILE_MAXU_L);      // the setup kernel never builds such a tile (and flags it if it did)
     const int nact = th->nact;
     TmCellRecK cells = (TmCellRecK)(a.cell + (size_t)chain * a.cells);
     TmActiveK tix = (TmActiveK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
@@ -393,7 +411,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     const double *__restrict__ lb = a.lx;
 
 #if defined(TM_ABLATE) && (TM_ABLATE & 32)   // timing-only build: prologue (scalar loads) only
-    if (nact >= 0 && N0 == N0) { if (tid == 0 && !GRAD) a.part[((size_t)chain * a.tiles + tile) * 2] = (double)(nh + row + u0 + (has_gauss ? 1 : 0)); return; }
+    if (nact >= 0 && N0 == N0) { if (tid == 0 && !GRAD) a.part[((size_t)chain * a.tiles + tile) * 4] = (double)(nh + row + u0 + (has_gauss ? 1 : 0)); return; }
 #endif
     // ---------------- pass 1: model spectrum and likelihood partial sums ----------------
     double S1 = 0.0;
@@ -632,27 +650,26 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
         if (GRAD) flush_noise(cur_cell - cell0);
     }
     TM_STAMP(1);
-    double S2 = 0.0;
-#if defined(TM_ABLATE) && (TM_ABLATE & 8)    // timing-only build: no log in the epilogue
-    S2 = P + (double)esum + (double)sgn;
-#else
+    // tile partials: S1 = sum y/M (or the chi-square sum), and sum log M as (mantissa product, exponent sum)
+    double Pm = 1.0, Pe = 0.0;
     if (a.likelihood_case == 0) {
-        S2 = log(P) + (double)esum * 0.693147180559945309417232;
-        if (sgn < 0) S2 = __builtin_nan("");
+        int e;
+        Pm = frexp(tm_wave_prod(P), &e);
+        Pe = tm_wave_sum((double)esum) + (double)e;
+        if (__builtin_amdgcn_ballot_w64(sgn < 0) != 0) Pm = __builtin_nan("");     // a negative model value anywhere: log -> NaN
     }
-#endif
     S1 = tm_wave_sum(S1);
-    S2 = tm_wave_sum(S2);
-    if (lane == 0) { s_red[0][wave][0] = S1; s_red[0][wave][1] = S2; }
+    if (lane == 0) { s_red[0][wave][0] = S1; s_red[0][wave][1] = Pm; s_red[0][wave][2] = Pe; }
     __syncthreads();
     if constexpr (GRAD) {
         if (tid == 0) {
-            double t1 = 0.0, t2 = 0.0;
+            double t1 = 0.0, tm = 1.0, te = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
-            double *out = a.part + ((size_t)chain * a.tiles + tile) * 2;   // summed by the backward kernel
+            for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; tm *= s_red[0][wv][1]; te += s_red[0][wv][2]; }
+            double *out = a.part + ((size_t)chain * a.tiles + tile) * 4;   // summed by the backward kernel
             out[0] = t1;
-            out[1] = t2;
+            out[1] = tm;
+            out[2] = te;
         }
     } else if (wave == 0) {
         // Finalize inside this launch: the workgroup that publishes the LAST tile partial of a chain sums all of them
@@ -665,18 +682,19 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
         // cost 18 us per launch here); it relies on these gfx9 properties, and tests/test_parity_gpu.py
         // (test_launch_order_does_not_change_results, run-to-run bitwise equality) is its guard.
         int last = 0;
-        double *pp = a.part + (size_t)chain * a.tiles * 2;
+        double *pp = a.part + (size_t)chain * a.tiles * 4;
         if (lane == 0) {
-            double t1 = 0.0, t2 = 0.0;
+            double t1 = 0.0, tm = 1.0, te = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; t2 += s_red[0][wv][1]; }
+            for (int wv = 0; wv < TM_WAVES; wv++) { t1 += s_red[0][wv][0]; tm *= s_red[0][wv][1]; te += s_red[0][wv][2]; }
 #if defined(TM_ABLATE) && (TM_ABLATE & 4)    // timing-only build: plain stores, no ticket, no finalize
-            pp[2 * tile] = t1; pp[2 * tile + 1] = t2;
+            pp[4 * tile] = t1; pp[4 * tile + 1] = tm; pp[4 * tile + 2] = te;
 #else
             if (a.tiles == 1) {
-                // the chain's only tile: nothing to hand over.  Same value as the general path below, which would add
-                // zeros to t1 and t2 (the other lanes' empty strides), without its store-drain-ticket-reload round trip
-                pp[0] = t1; pp[1] = t2;
+                // the chain's only tile: nothing to hand over.  Same value as the general path below, without its
+                // store-drain-ticket-reload round trip
+                pp[0] = t1; pp[1] = tm; pp[2] = te;
+                const double t2 = (a.likelihood_case == 0) ? tm_tile_logsum(tm, te) : 0.0;
                 double f = (a.likelihood_case == 0) ? -a.like_p * (t1 + t2) : -t1;
                 f = f / a.wt[2 * chain];
                 int st = a.noise[chain].status;
@@ -685,8 +703,9 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                 a.logL[chain] = f;
                 if (a.status) a.status[chain] = st;
             } else {
-            __hip_atomic_store(pp + 2 * tile, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pp + 2 * tile + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 4 * tile, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 4 * tile + 1, tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 4 * tile + 2, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int prev = __hip_atomic_fetch_add(a.ticket + chain, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (prev == a.tiles - 1) ? 1 : 0;
@@ -697,8 +716,10 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
         if (last) {
             double s1 = 0.0, s2 = 0.0;
             for (int t = lane; t < a.tiles; t += 64) {
-                s1 += __hip_atomic_load(pp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s2 += __hip_atomic_load(pp + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s1 += __hip_atomic_load(pp + 4 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.likelihood_case == 0)
+                    s2 += tm_tile_logsum(__hip_atomic_load(pp + 4 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                         __hip_atomic_load(pp + 4 * t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
             s1 = tm_wave_sum(s1);
             s2 = tm_wave_sum(s2);

@@ -47,7 +47,7 @@ int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a
     hipStream_t stream = (hipStream_t)stream_;
     const int units = tm_units(a.Nx);
     const size_t lds = ((size_t)f.p_doubles + (grad ? (size_t)units * TM_UNIT_BINS : 1)) * sizeof(double);
-    TmCostModel cm{0, 0, 0, 0};
+    TmCostModel cm{0, 0, 0, TM_TILE_MAXU};
     if (grad) hipLaunchKernelGGL((tamcmc_fused_kernel<true>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a, cm);
     else      hipLaunchKernelGGL((tamcmc_fused_kernel<false>), dim3(Nchains), dim3(TM_THREADS), lds, stream, L, f, a, cm);
     return (int)hipGetLastError();

@@ -16,7 +16,7 @@ template <int NT>
 __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain, const double *__restrict__ params,
                                               const double *__restrict__ Tcoefs, double *__restrict__ wt,
                                               const double *__restrict__ lx, int units, int cells, int tiles, int equal_cost,
-                                              const TmCostModel cm, TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
+                                              const TmCostModel cm /* cm.pad: units per tile at most */, TmMult *__restrict__ mult, TmNoise *__restrict__ noise,
                                               TmCellRec *__restrict__ cell, TmTileHdr *__restrict__ thdr, TmActive *__restrict__ tidx,
                                               TmChain *__restrict__ chain_rec, TmMultFull *__restrict__ aux,
                                               double *__restrict__ hser, int32_t *__restrict__ order, double *p,
@@ -240,7 +240,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         int u0, u1;
         if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
         else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
-        if (u1 - u0 > TM_TILE_MAXU) { u1 = u0 + TM_TILE_MAXU; atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
+        if (u1 - u0 > cm.pad) { u1 = u0 + cm.pad; atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
         const int base = u0 << TM_UNIT_SHIFT, end = u1 << TM_UNIT_SHIFT;
         TmActive *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
         int nact = 0, cost = 0;
