@@ -190,18 +190,27 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const TmMultFull &M = auxp[j];
         double acc = 0.0;
         if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
-            // tiles whose units meet the window's units [ua, ub] (the multiplet is on their active lists): the first one
-            // is the tile holding unit ua -- the last tile that starts at or before it (binary search over the tile
-            // starts; empty tiles share a start with their successor and are passed over by taking the last)
+            // tiles whose units meet the window's units [ua, ub] (the multiplet is on their active lists).  Tiles of equal
+            // length (the default) are found by division; per-chain boundaries (equal-cost tiles) by a search over the
+            // tile starts: the first one is the tile holding unit ua -- the last tile that starts at or before it (empty
+            // tiles share a start with their successor and are passed over by taking the last).
             const int ua = M.imin >> TM_UNIT_SHIFT, ub = (M.imax - 1) >> TM_UNIT_SHIFT;
-            int lo = 0, hi = tiles - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_u[mid] <= ua) lo = mid; else hi = mid - 1;
+            if (s_u[1] * (tiles - 1) == s_u[tiles - 1] && s_u[1] > 0) {
+                const int su = s_u[1], tA = ua / su, tB = (ub / su < tiles - 1) ? ub / su : tiles - 1;
+                const double *G = gmult + (((size_t)chain * tiles + tA) * nm + j) * TM_GSLOTS + sl;
+                const size_t stride = (size_t)nm * TM_GSLOTS;
+#pragma unroll 4
+                for (int t = tA; t <= tB; t++) acc += G[(size_t)(t - tA) * stride];
+            } else {
+                int lo = 0, hi = tiles - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_u[mid] <= ua) lo = mid; else hi = mid - 1;
+                }
+                for (int t = lo; t < tiles && s_u[t] <= ub; t++)
+                    if (s_u[t + 1] > s_u[t] && s_u[t + 1] > ua)
+                        acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
             }
-            for (int t = lo; t < tiles && s_u[t] <= ub; t++)
-                if (s_u[t + 1] > s_u[t] && s_u[t + 1] > ua)
-                    acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
         }
         s_G[item] = acc;
     }

