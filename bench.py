@@ -305,22 +305,6 @@ def run_rank(args):
         smp.close()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pyoracle as orc       # reported baseline only; never on the product path
-        cores = orc.max_threads()
-        Pc, Tc = P_all[sl], T_all[sl]
-        orc.generate_batch(2, w["plength"], w["x"], y, Pc, Tc)          # warm-up
-        n_it, t0 = 0, time.perf_counter()
-        while True:
-            orc.generate_batch(2, w["plength"], w["x"], y, Pc, Tc)
-            n_it += 1
-            el = time.perf_counter() - t0
-            if el >= args.cpu_seconds or n_it >= 2000:
-                break
-        cpu = {"value": round(nchains * n_it / el, 2), "unit": "chain-steps/s", "cores": int(cores), "kind": "port",
-               "sample": f"{n_it} iterations x {nchains} chains x {args.nx} bins, logL only (the reference has no "
-                         f"gradient), OpenMP over chains, {el:.1f} s"}
-
     out = None
     if rank == 0:
         out = {
@@ -364,6 +348,24 @@ def run_rank(args):
             if rank == 0:
                 out["sampler_sharded"] = {"error": f"{type(e).__name__}: {e}"}
         dog.cancel()
+
+    # the CPU baseline last: its OpenMP threads (one per host core) would otherwise still be spinning beside the sampler legs
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as orc       # reported baseline only; never on the product path
+        cores = orc.max_threads()
+        Pc, Tc = P_all[sl], T_all[sl]
+        orc.generate_batch(2, w["plength"], w["x"], y, Pc, Tc)          # warm-up
+        n_it, t0 = 0, time.perf_counter()
+        while True:
+            orc.generate_batch(2, w["plength"], w["x"], y, Pc, Tc)
+            n_it += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds or n_it >= 2000:
+                break
+        out["cpu_baseline"] = cpu = {"value": round(nchains * n_it / el, 2), "unit": "chain-steps/s", "cores": int(cores), "kind": "port",
+               "sample": f"{n_it} iterations x {nchains} chains x {args.nx} bins, logL only (the reference has no "
+                         f"gradient), OpenMP over chains, {el:.1f} s"}
+
     emit()
     acc.close()
     if dist is not None:

@@ -568,7 +568,11 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                 const double wk = wreg[k];
                 s_w[((u - u0) * 2 + h0 + k) * TM_THREADS + tid] = wk;
                 gn_[3 * TM_MAXH] += wk;
+#if defined(TM_ABLATE) && (TM_ABLATE & 512)   // timing-only build: no weight moments
+                if (false) {
+#else
                 if (nh > 0 && npoly) {
+#endif
                     // moments of the weights about the cell centre: slot j-1 <- sum w dl^j, j = 1..TM_HSER-1
                     double q = wk;
 #pragma unroll
