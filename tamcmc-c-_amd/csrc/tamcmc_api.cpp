@@ -43,7 +43,7 @@ struct tamcmc_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // resident data
-    double *d_x = nullptr, *d_y = nullptr, *d_lx = nullptr, *d_isig2 = nullptr;
+    double *d_x2 = nullptr, *d_y = nullptr, *d_lx = nullptr, *d_isig2 = nullptr;   // 2 x, y, log x, 1 / sigma^2
     int nspec = 1;                 // spectra resident in d_y / d_isig2 (blocks of Nx); tamcmc_ctx_set_spectra
     int32_t *d_spec = nullptr;     // [spec_n] chain -> spectrum map (tamcmc_ctx_set_chain_spectrum), or NULL: all chains use spectrum 0
     int spec_n = 0;
@@ -286,13 +286,14 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(TAMCMC_E_HIP);
     c->stream = c->own_stream;
     const size_t bytes = (size_t)Nx * sizeof(double);
-    if (hipMalloc(&c->d_x, bytes) != hipSuccess || hipMalloc(&c->d_y, bytes) != hipSuccess ||
+    if (hipMalloc(&c->d_x2, bytes) != hipSuccess || hipMalloc(&c->d_y, bytes) != hipSuccess ||
         hipMalloc(&c->d_lx, bytes) != hipSuccess)
         return fail(TAMCMC_E_NOMEM);
     std::vector<double> tmp((size_t)Nx);
+    for (int64_t i = 0; i < Nx; i++) tmp[(size_t)i] = 2.0 * x[i];        // exact; the Lorentzians are written in d = 2x - 2nu
+    if (hipMemcpy(c->d_x2, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(TAMCMC_E_HIP);
     for (int64_t i = 0; i < Nx; i++) tmp[(size_t)i] = std::log(x[i]);   // log x table for the Harvey powers
-    if (hipMemcpy(c->d_x, x, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_y, y, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(c->d_y, y, bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->d_lx, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
         return fail(TAMCMC_E_HIP);
     if (likelihood_case == 1) {
@@ -310,7 +311,7 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_batch(c);
-    (void)hipFree(c->d_x); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2); (void)hipFree(c->d_spec);
+    (void)hipFree(c->d_x2); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2); (void)hipFree(c->d_spec);
     (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
     (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
     if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
@@ -491,7 +492,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const int tiles = pick_tiles(c, Nchains, grad);
     if (!grad) c->last_tiles = tiles;
     TmEvalArgs a{};
-    a.x = c->d_x; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
+    a.x2 = c->d_x2; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
     a.spec = (c->nspec > 1) ? c->d_spec : nullptr;
     a.mult = c->d_mult; a.noise = c->d_noise; a.cell = c->d_cell; a.thdr = c->d_thdr; a.tidx = c->d_tidx; a.wt = c->d_wt;
     a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;

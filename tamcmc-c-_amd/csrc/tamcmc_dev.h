@@ -1,7 +1,7 @@
 // tamcmc_dev.h -- structures shared by the host side of the C ABI and the gfx950 kernels.
 //
 // Data layout in HBM (all fp64 unless noted), one set per ctx (= one star on one GPU):
-//   x[Nx], y[Nx], lx[Nx]=log(x), isig2[Nx]=1/sigma_y^2 (chi_square only)      resident, written at create
+//   x2[Nx]=2x, y[Nx], lx[Nx]=log(x), isig2[Nx]=1/sigma_y^2 (chi_square only)   resident, written at create
 //   params[Nchains][Nparams], Tcoefs[Nchains]                                 per call (or caller-resident)
 //   mult[Nchains][n_mult]   : TmMult  -- per-chain multiplet table written by the setup kernel
 //   noise[Nchains]          : TmNoise -- Harvey / white-noise / Gaussian terms per chain
@@ -126,7 +126,7 @@ struct TmCostModel {
 };
 
 struct TmEvalArgs {
-    const double *x, *y, *lx, *isig2;
+    const double *x2, *y, *lx, *isig2;   // x2 = 2 x (the kernels only ever need d = 2x - 2nu), log x, 1 / sigma^2
     const TmMult *mult;
     const TmNoise *noise;
     const TmCellRec *cell;      // [Nchains][cells]

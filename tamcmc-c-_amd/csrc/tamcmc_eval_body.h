@@ -32,6 +32,16 @@ __device__ __forceinline__ double tm_rcp(double x)
     return r;
 }
 
+// The same with one Newton step: 2.2e-15 relative (tools/rcp_accuracy.hip).  Used by pass 2 of the gradient kernel only
+// -- the gradient is new functionality checked against finite differences (2e-5), and its sums carry cancellation far
+// above that level; everything that enters logL keeps the two-step form.
+__device__ __forceinline__ double tm_rcp1(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 // ---- lane exchanges without LDS traffic -----------------------------------------------------------
 // __shfl_xor compiles to ds_bpermute_b32 (two per double, through the LDS crossbar); the reductions of the gradient
 // pass issue ~50 of them per multiplet and wave and were bound by that path (profiles/README.md).  gfx950 has
@@ -180,7 +190,7 @@ __device__ __forceinline__ double tm_mult_value(double x2, const double (&nu2)[N
     P[0] = E[0];
 #pragma unroll
     for (int m = 1; m < NC; m++) P[m] = P[m - 1] * E[m];
-    double inv = tm_rcp(P[NC - 1]);
+    double inv = tm_rcp1(P[NC - 1]);
     double s = 0.0;
 #pragma unroll
     for (int m = NC - 1; m >= 1; m--) {
@@ -278,10 +288,10 @@ __device__ __forceinline__ void tm_grad_unit(const double (&nu2)[NC], const doub
         if (edge) {
             const int i = i0 + k * TM_THREADS;
             const bool inside = (i >= imin) && (i < imax) && (i < Nx);
-            x2 = 2.0 * gx[i < Nx ? i : Nx - 1];
+            x2 = gx[i < Nx ? i : Nx - 1];
             wk = inside ? wq[k * TM_THREADS] : 0.0;
         } else {
-            x2 = 2.0 * gx[i0 + k * TM_THREADS];
+            x2 = gx[i0 + k * TM_THREADS];
             wk = wq[k * TM_THREADS];
         }
         double d[NC], r[NC];
@@ -407,7 +417,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
     // FULL groups address the grid as (wave-uniform base pointer) + (32-bit per-thread bin index): global loads with a
     // scalar base and one VGPR of offset, instead of one 64-bit pointer per array and thread (Nx < 2^28 is checked at create)
-    const double *__restrict__ xb = a.x;
+    const double *__restrict__ xb = a.x2;
     const double *__restrict__ lb = a.lx;
 
 #if defined(TM_ABLATE) && (TM_ABLATE & 32)   // timing-only build: prologue (scalar loads) only
@@ -435,11 +445,11 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
             const int i = lo + k * TM_THREADS + tid;
             if (FULL) {
                 bi[k] = i;
-                x2[k] = 2.0 * xb[(unsigned)i];
+                x2[k] = xb[(unsigned)i];
             } else {
                 const bool valid = i < a.Nx;
                 bi[k] = valid ? i : -1;
-                x2[k] = 2.0 * a.x[valid ? i : a.Nx - 1];
+                x2[k] = a.x2[valid ? i : a.Nx - 1];
             }
             acc[k] = 0.0;
         }
@@ -764,14 +774,14 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
             double *red = s_red[(jj + 1) & 1][wave];
             if (shape < 256 && lane == 0) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
             switch (shape) {
-            case 1: tm_grad_mult<1, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            case 3: tm_grad_mult<3, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            case 5: tm_grad_mult<5, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            case 7: tm_grad_mult<7, false>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            case 256 + 1: tm_grad_mult<1, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            case 256 + 3: tm_grad_mult<3, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            case 256 + 5: tm_grad_mult<5, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
-            default: tm_grad_mult<7, true>(sm, a.x, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 1: tm_grad_mult<1, false>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 3: tm_grad_mult<3, false>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 5: tm_grad_mult<5, false>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 7: tm_grad_mult<7, false>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 256 + 1: tm_grad_mult<1, true>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 256 + 3: tm_grad_mult<3, true>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            case 256 + 5: tm_grad_mult<5, true>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
+            default: tm_grad_mult<7, true>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
             }
 #if defined(TM_ABLATE) && (TM_ABLATE & 64)   // timing-only build: no workgroup barrier per multiplet (wave 0 publishes its own partial)
             if (tid < TM_GSLOTS) a.gmult[(((size_t)chain * a.tiles + tile) * a.n_mult + idx) * TM_GSLOTS + tid] = red[tid];
