@@ -22,6 +22,17 @@
  * There is NO CPU fallback: without a usable HIP device tamcmc_ctx_create fails with
  * TAMCMC_E_NODEVICE.
  *
+ * Environment switches read by tamcmc_ctx_create (developer knobs; none is needed in normal use, none changes a result
+ * beyond rounding, and the tests exercise every one of them):
+ *   TAMCMC_TILES, TAMCMC_TILES_GRAD   tiles per chain of the likelihood-only / gradient launch (default 8 units of 512 bins)
+ *   TAMCMC_EQUAL_COST=1               per-chain tile boundaries of equal cost instead of equal length
+ *   TAMCMC_COST, TAMCMC_COST_GRAD     "c0,a,b": the balancer's cost model
+ *   TAMCMC_PRIO=1                     issue priority by launch rank
+ *   TAMCMC_ORDER=0|1|2                launch order (default 2: tile-major, each chain's tiles costliest-first)
+ *   TAMCMC_FUSED=0                    one-tile grids: prologue and evaluation as two launches instead of one
+ *   TAMCMC_BG_EXACT=1                 Harvey background by exp() per bin instead of the per-cell polynomial
+ * (tamcmc_sampler.h: TAMCMC_SAMPLER_THREADS, TAMCMC_SAMPLER_TIMING.)
+ *
  * Threading: one ctx = one device + one stream; calls on one ctx must be serialised by the caller;
  * different ctx objects (other GPUs, other stars) may be driven concurrently from different threads.
  * Ownership: the library copies x, y, sigma_y to the device at create time and never keeps caller

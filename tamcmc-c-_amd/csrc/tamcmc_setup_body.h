@@ -236,30 +236,50 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         }
         __syncthreads();
     }
-    // the multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel)
-    for (int tile = tid; tile < tiles; tile += NT) {
-        int u0, u1;
-        if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
-        else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
-        if (u1 - u0 > cm.pad) { u1 = u0 + cm.pad; atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
-        const int base = u0 << TM_UNIT_SHIFT, end = u1 << TM_UNIT_SHIFT;
-        TmActive *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
-        int nact = 0, cost = 0;
-        if (u1 > u0)
-            for (int j = 0; j < nm; j++)
-                if (s_win[j][0] < end && s_win[j][1] > base) {
+    // The multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel).
+    // One WAVE per tile, one lane per multiplet: the windows come out of LDS side by side, a ballot compacts the active
+    // ones in table order, and the tile's cost comes from ballots per component count -- scalar popcounts, no exchange
+    // between lanes (a lane walking a tile's multiplets one after the other took 3 us of dependent LDS round trips).
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        constexpr int NW = NT / 64;
+        for (int tile = wv; tile < tiles; tile += NW) {
+            int u0, u1;
+            if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
+            else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
+            if (u1 - u0 > cm.pad) { u1 = u0 + cm.pad; if (lane == 0) atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
+            const int base = u0 << TM_UNIT_SHIFT, end = u1 << TM_UNIT_SHIFT;
+            TmActive *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
+            const int asym_bit = (C.asym != 0) ? 256 : 0;
+            int nact = 0, cost = 0;
+            for (int j0 = 0; j0 < nm && u1 > u0; j0 += 64) {
+                const int j = j0 + lane;
+                int wmin = 0, wmax = 0, nc = 0;
+                if (j < nm) { wmin = s_win[j][0]; wmax = s_win[j][1]; nc = s_win[j][2]; }
+                const bool act = (j < nm) && (wmin < end) && (wmax > base);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
+                if (act) {
                     TmActive A;
-                    A.idx = j; A.imin = s_win[j][0]; A.imax = s_win[j][1]; A.shape = s_win[j][2] | (C.asym != 0 ? 256 : 0);
-                    ti[nact++] = A;
-                    const int lo = s_win[j][0] > base ? s_win[j][0] : base, hi = s_win[j][1] < end ? s_win[j][1] : end;
-                    cost += (cm.a * s_win[j][2] + cm.b) * ((hi - lo + 255) >> 8);     // ~ instructions, in units of 256 bins
+                    A.idx = j; A.imin = wmin; A.imax = wmax; A.shape = nc | asym_bit;
+                    ti[nact + __builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = A;
                 }
-        cost += cm.c0 * 2 * (u1 - u0);
-        TmTileHdr H;
-        H.u0 = u0; H.u1 = u1; H.nact = nact; H.cost = cost;
-        thdr[(size_t)chain * tiles + tile] = H;
-        // unique key: cost first, lower tile index first among equals
-        if (tile < TM_ORDER_MAX) s_cost[tile] = ((cost < (1 << 20) ? cost : (1 << 20)) << 10) + (TM_ORDER_MAX - 1 - tile);
+                nact += __builtin_popcountll(m);
+                // cost ~ instructions per bin of the tile's multiplets (a * ncomp + b each), from ballots per component count
+                const int n3 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && nc == 3));
+                const int n5 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && nc == 5));
+                const int n7 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && nc == 7));
+                const int na = __builtin_popcountll(m);
+                cost += cm.a * ((na - n3 - n5 - n7) + 3 * n3 + 5 * n5 + 7 * n7) + cm.b * na;
+            }
+            cost = (cost + cm.c0) * 2 * (u1 - u0);
+            if (lane == 0) {
+                TmTileHdr H;
+                H.u0 = u0; H.u1 = u1; H.nact = nact; H.cost = cost;
+                thdr[(size_t)chain * tiles + tile] = H;
+                // unique key: cost first, lower tile index first among equals
+                if (tile < TM_ORDER_MAX) s_cost[tile] = ((cost < (1 << 20) ? cost : (1 << 20)) << 10) + (TM_ORDER_MAX - 1 - tile);
+            }
+        }
     }
     // launch order of this chain's tiles: costliest first (rank = number of tiles with a larger key)
     if (order != nullptr) {
