@@ -1,5 +1,5 @@
 """Occupancy guard: the eval kernels sit right at a register-file step (gradient: 128 VGPRs = 4 waves/SIMD, one more
-register drops to 3; likelihood: 64 VGPRs = 8 waves/SIMD).  A harmless-looking edit has crossed that step before and cost
+register drops to 3; likelihood: 72 VGPRs = 7 waves/SIMD, which its 106 SGPRs allow anyway).  A harmless-looking edit has crossed that step before and cost
 8 % of the headline rate, so the cross-compiled resource usage is checked on the CPU."""
 import os
 import re
@@ -23,4 +23,4 @@ def test_eval_kernel_register_budget():
     fwd = [v for k, v in usage.items() if "tamcmc_eval_kernelILb0" in k]
     assert grad and fwd, txt[-2000:]
     assert grad[0][0] <= 128 and grad[0][1] == 0 and grad[0][2] == 0, grad
-    assert fwd[0][0] <= 64 and fwd[0][1] == 0 and fwd[0][2] == 0, fwd
+    assert fwd[0][0] <= 72 and fwd[0][1] == 0 and fwd[0][2] == 0, fwd
