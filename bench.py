@@ -186,10 +186,13 @@ def run_rank(args):
         ghz, sec = acc.clock_probe_end()
         return ghz
 
+    # HIP events around every 4th eval launch of the timed region (an event pair costs ~3 us of stream time: around every
+    # launch it took 5 % off `value`)
+    ev_stride = 4 if args.steps >= 8 else 1
     prewarm(True)
     for _ in range(args.warmup):
         step(True)
-    acc.profile(True)
+    acc.profile(ev_stride)
     dt = timed(args.steps, True)
     k_ms, k_n = acc.kernel_time()
     acc.profile(False)
@@ -201,7 +204,7 @@ def run_rank(args):
     prewarm(False)
     for _ in range(max(2, args.warmup // 4)):
         step(False)
-    acc.profile(True)
+    acc.profile(ev_stride)
     dt_l = timed(args.steps, False)
     kl_ms, kl_n = acc.kernel_time()
     acc.profile(False)
@@ -242,7 +245,7 @@ def run_rank(args):
     roofline = {
         "bound": "fp64-valu", "kernel": "tamcmc_eval_kernel<grad>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "kernel_ms": round(k_avg_s * 1e3, 4), "launches": int(k_n),
+        "kernel_ms": round(k_avg_s * 1e3, 4), "launches": int(k_n), "launches_timed_every": ev_stride,
         "note": "achieved / peak / frac are the algorithmic bytes (16 B x Nx x chains) against the HBM peak, as the north-star "
                 "asks; the kernel is bound by fp64 VALU issue (SURVEY.md F6): x / y are shared by all chains through L2, so measured "
                 "HBM traffic (FETCH_SIZE doubled per the gfx950 calibration, + WRITE_SIZE) is ~4x below the algorithmic bytes",

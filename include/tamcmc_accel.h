@@ -137,8 +137,9 @@ int tamcmc_model_explicit(tamcmc_ctx *ctx, int32_t Nparams, const double *params
 int tamcmc_ctx_set_stream(tamcmc_ctx *ctx, void *hip_stream);
 int tamcmc_ctx_synchronize(tamcmc_ctx *ctx);
 
-/* Kernel timing with HIP events recorded on the ctx stream around the dominant kernel of every
- * eval call while enabled.  tamcmc_ctx_kernel_time synchronises the stream, then returns the summed
+/* Kernel timing with HIP events recorded on the ctx stream around the dominant kernel of every eval call while
+ * enabled (enable = 1), or of every n-th call (enable = n > 1: an event pair costs ~3 us of stream time, which a
+ * throughput measurement over the same calls would otherwise carry in full).  tamcmc_ctx_kernel_time synchronises the stream, then returns the summed
  * duration and the number of launches since profiling was enabled. */
 int tamcmc_ctx_profile(tamcmc_ctx *ctx, int enable);
 int tamcmc_ctx_kernel_time(tamcmc_ctx *ctx, double *total_ms, int64_t *launches);

@@ -202,7 +202,7 @@ class Accel:
         self._check(self._lib.tamcmc_ctx_synchronize(self._ctx), "tamcmc_ctx_synchronize")
 
     def profile(self, enable=True):
-        self._check(self._lib.tamcmc_ctx_profile(self._ctx, 1 if enable else 0), "tamcmc_ctx_profile")
+        self._check(self._lib.tamcmc_ctx_profile(self._ctx, int(enable)), "tamcmc_ctx_profile")
 
     def kernel_time(self):
         ms = C.c_double(0.0)

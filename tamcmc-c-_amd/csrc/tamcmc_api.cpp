@@ -82,6 +82,8 @@ struct tamcmc_ctx {
     unsigned long long *h_probe = nullptr, *dv_probe = nullptr;   // pinned: {core cycles, 100 MHz ticks}
     // profiling
     bool profile = false;
+    int profile_stride = 1;       // events around every n-th eval launch (tamcmc_ctx_profile(ctx, n))
+    long long profile_count = 0;
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
     size_t ev_used = 0;
 };
@@ -401,6 +403,8 @@ extern "C" int tamcmc_ctx_profile(tamcmc_ctx *c, int enable)
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
     c->profile = enable != 0;
+    c->profile_stride = enable > 1 ? enable : 1;
+    c->profile_count = 0;
     c->ev_used = 0;
     return TAMCMC_OK;
 }
@@ -512,7 +516,8 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
                              grad ? c->d_hser : nullptr, a.order_mode == 2 ? c->d_order : nullptr, c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }
-    if (c->profile) {
+    const bool timed = c->profile && (c->profile_count++ % c->profile_stride == 0);
+    if (timed) {
         while (c->ev.size() < c->ev_used + 2) {
             hipEvent_t e;
             TM_HIP(hipEventCreate(&e));
@@ -534,7 +539,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
         (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);   // arrival counters back to zero
         return TAMCMC_E_HIP;
     }
-    if (c->profile) {
+    if (timed) {
         TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
     }
