@@ -18,7 +18,8 @@
  * proposal is not being adapted.  MaxChain = 24 (MALA.cpp:565-572) is not enforced.
  *
  * Sharded runs (one process per GPU): every rank creates the sampler with the GLOBAL chain count and its
- * own [chain_offset, chain_offset + n_local) block; every rank consumes the whole random stream, so the
+ * own [chain_offset, chain_offset + n_local) block; every rank consumes the whole random stream (the draws of
+ * chains owned elsewhere are passed over by a jump-ahead of the generator, not made), so the
  * chains are bit-identical to a single-process run.  A parallel-tempering pair that straddles two ranks
  * is exchanged by the caller (torch.distributed send/recv) through tamcmc_sampler_pt_* below.
  */
@@ -152,6 +153,9 @@ double tamcmc_log_prior(int32_t prior_fct_switch, int32_t Nparams, const double 
 void tamcmc_normals(uint32_t seed, int32_t ncalls, const int32_t *sizes, double *out, int32_t split);
 /* the private copy of glibc's rand(): fills out[n] after srand(seed) (test hook) */
 void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out);
+/* the same after `skip` values were passed over by the generator's jump-ahead (a sharded sampler jumps over the draws of
+ * the chains other processes own): must equal tamcmc_glibc_rand's values skip .. skip + n - 1 (test hook) */
+void tamcmc_glibc_rand_jump(uint32_t seed, uint64_t skip, int32_t n, int32_t *out);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // reference.  Plain C++17, no Eigen: matrices are row-major std::vector<double>.
 #include "tamcmc_sampler.h"
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -247,6 +248,57 @@ struct GlibcRand {
         if (++f >= 31) f = 0;
         if (++b >= 31) b = 0;
         return out;
+    }
+    // Jump ahead: the state after k more calls of next(), without making them.  The words obey z[n] = z[n-31] + z[n-3]
+    // modulo 2^32, a linear recurrence with characteristic polynomial p(x) = x^31 - x^28 - 1, so with
+    // G(x) = x^k mod p(x) = sum_j G_j x^j every later word is z[m + k] = sum_j G_j z[m + j].  G costs ~31^2 log2(k)
+    // multiply-adds and is kept per k (a sharded sampler skips the same few distances every iteration); applying it
+    // costs 30 ordinary steps (the window z[m .. m + 60]) and 31 x 31 multiply-adds.
+    void jump(uint64_t k)
+    {
+        if (k < 64) { for (uint64_t i = 0; i < k; i++) (void)next(); return; }
+        static thread_local std::vector<std::pair<uint64_t, std::array<uint32_t, 31>>> cache;
+        const std::array<uint32_t, 31> *G = nullptr;
+        for (const auto &e : cache) if (e.first == k) { G = &e.second; break; }
+        if (!G) {
+            auto reduce = [](uint32_t (&c)[61]) {      // x^31 = x^28 + 1
+                for (int d = 60; d >= 31; d--) { c[d - 3] += c[d]; c[d - 31] += c[d]; c[d] = 0; }
+            };
+            uint32_t g[61] = {0};
+            g[0] = 1;                                   // x^0
+            int top = 63;
+            while (top > 0 && !((k >> top) & 1)) top--;
+            for (int bit = top; bit >= 0; bit--) {
+                uint32_t sq[61] = {0};
+                for (int i = 0; i < 31; i++)
+                    if (g[i]) for (int j = 0; j < 31; j++) sq[i + j] += g[i] * g[j];
+                reduce(sq);
+                if ((k >> bit) & 1) {                   // times x
+                    for (int d = 31; d >= 1; d--) sq[d] = sq[d - 1];
+                    sq[0] = 0;
+                    reduce(sq);
+                }
+                for (int i = 0; i < 61; i++) g[i] = sq[i];
+            }
+            std::array<uint32_t, 31> a;
+            for (int i = 0; i < 31; i++) a[i] = g[i];
+            if (cache.size() >= 16) cache.erase(cache.begin());
+            cache.emplace_back(k, a);
+            G = &cache.back().second;
+        }
+        // window of the sequence: z[0 .. 30] = the 31 words in age order (oldest first), z[31 .. 60] = the next 30
+        uint32_t z[61];
+        for (int i = 0; i < 31; i++) z[i] = (uint32_t)r[(f + i) % 31];
+        for (int i = 31; i < 61; i++) z[i] = z[i - 31] + z[i - 3];
+        uint32_t w[31];
+        for (int t = 0; t < 31; t++) {
+            uint32_t acc = 0;
+            for (int j = 0; j < 31; j++) acc += (*G)[j] * z[t + j];
+            w[t] = acc;                                 // z[t + k]
+        }
+        // the state after k steps, in the same ring layout: the pointers advance by k, the words in age order are w
+        f = (int)((f + k) % 31); b = (int)((b + k) % 31);
+        for (int i = 0; i < 31; i++) r[(f + i) % 31] = (int32_t)w[i];
     }
 };
 
@@ -661,19 +713,40 @@ static inline double wall_now() { return std::chrono::duration<double>(std::chro
 // Every process consumes the WHOLE stream (that is what makes a sharded run the single-process run, bit for bit), so
 // the draws of the chains owned elsewhere are a serial term that grows with the global chain count while the GPU work
 // per process shrinks; t_phase[6] keeps its share (tamcmc_sampler_get_timing) so that a sharded bench can report it.
+// The raw stream of `count` chains owned elsewhere (for each: one uniform, then what r8vec_normal_01(Nvars) consumes:
+// Nvars uniforms, one fewer when a value is carried in, rounded up to an even number, random_JB.cpp:134-209) is passed
+// over by a jump of the generator -- except the last chain, which is drawn: whether it leaves a carried value, and
+// which, is all the next chain can see of it (a carried value never travels further than one chain).
+static void skip_foreign(tamcmc_sampler *s, int count)
+{
+    const int nv = s->Nvars, n = s->nloc;
+    if (count <= 0) return;
+    uint64_t K = 0;
+    int saved = s->rng.saved;
+    for (int c = 0; c + 1 < count; c++) {
+        K += 1;
+        const int cnt = nv - (saved ? 1 : 0);
+        saved = 0;
+        if (cnt > 0) { const int odd = cnt & 1; K += (uint64_t)(odd ? cnt + 1 : cnt); saved = odd; }
+    }
+    if (count > 1) { s->rng.g.jump(K); s->rng.saved = saved; s->rng.y = 0.0; }   // y: only the chain drawn next sees it, and that chain is not ours
+    (void)s->rng.uniform();
+    s->rng.draw(nv, s->plans[(size_t)n]);
+}
+
 static void draw_mh(tamcmc_sampler *s)
 {
     const int n = s->nloc, nv = s->Nvars, off = s->cfg.chain_offset, N = s->cfg.Nchains;
     const bool tm = s->timing && n < N;
     double t0 = tm ? wall_now() : 0.0;
-    for (int g = 0; g < off; g++) { (void)s->rng.uniform(); s->rng.draw(nv, s->plans[(size_t)n]); }
+    skip_foreign(s, off);
     if (tm) { const double t1 = wall_now(); s->t_phase[6] += t1 - t0; }
     for (int m = 0; m < n; m++) {
         s->u_mh[m] = s->rng.uniform();
         s->rng.draw(nv, s->plans[(size_t)m]);
     }
     if (tm) t0 = wall_now();
-    for (int g = off + n; g < N; g++) { (void)s->rng.uniform(); s->rng.draw(nv, s->plans[(size_t)n]); }
+    skip_foreign(s, N - off - n);
     if (tm) { const double t1 = wall_now(); s->t_phase[6] += t1 - t0; }
 }
 
@@ -1127,6 +1200,14 @@ extern "C" void tamcmc_normals(uint32_t seed, int32_t ncalls, const int32_t *siz
         else rng.normals(sizes[c], out);
         out += sizes[c];
     }
+}
+
+extern "C" void tamcmc_glibc_rand_jump(uint32_t seed, uint64_t skip, int32_t n, int32_t *out)
+{
+    GlibcRand g;
+    g.seed(seed);
+    g.jump(skip);
+    for (int i = 0; i < n; i++) out[i] = g.next();
 }
 
 extern "C" void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out)

@@ -64,6 +64,8 @@ def _lib():
         lib.tamcmc_normals.restype = None
         lib.tamcmc_glibc_rand.argtypes = [C.c_uint32, C.c_int32, ip]
         lib.tamcmc_glibc_rand.restype = None
+        lib.tamcmc_glibc_rand_jump.argtypes = [C.c_uint32, C.c_uint64, C.c_int32, ip]
+        lib.tamcmc_glibc_rand_jump.restype = None
         _BOUND = True
     return lib
 
@@ -98,6 +100,12 @@ def log_prior(prior_fct_switch, params, plength, priors_names_switch, priors_par
 def glibc_rand(seed, n):
     out = np.empty(n, dtype=np.int32)
     _lib().tamcmc_glibc_rand(int(seed), n, _ip(out))
+    return out
+
+
+def glibc_rand_jump(seed, skip, n):
+    out = np.empty(n, dtype=np.int32)
+    _lib().tamcmc_glibc_rand_jump(int(seed), int(skip), n, _ip(out))
     return out
 
 

@@ -102,6 +102,18 @@ def test_priors_local():
 
 
 # ---------------------------------------------------------------- RNG
+def test_rand_jump_ahead_equals_stepping():
+    """GlibcRand::jump (x^k modulo the generator's characteristic polynomial, tamcmc_sampler.cpp): a sharded sampler
+    passes over the draws of the chains other processes own without making them.  Every distance -- below the
+    threshold where it just steps, powers of two, the distances a 45-variable 64-chain block gives -- must land on the
+    value plain stepping reaches."""
+    for seed in (1, 99, 2**31 + 7):
+        ref = S.glibc_rand(seed, 70000)
+        for skip in (0, 1, 30, 31, 63, 64, 65, 127, 1000, 2898, 2944, 4096, 12345, 65536):
+            got = S.glibc_rand_jump(seed, skip, 200)
+            assert np.array_equal(got, ref[skip:skip + 200]), (seed, skip)
+
+
 def test_private_rand_is_glibc_rand():
     libc = ctypes.CDLL(None)
     for seed in (1, 12345, 2**31 + 7):

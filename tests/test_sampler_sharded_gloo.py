@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-NCH, NIT = 6, 60
+NIT = 60
 
 
 def _setup():
@@ -28,7 +28,7 @@ def _setup():
     return w, sw, pp, y, orc, tps
 
 
-def _make(offset, nloc):
+def _make(offset, nloc, NCH):
     from tamcmc_amd import sampler as S
     w, sw, pp, y, orc, tps = _setup()
     cfg = S.default_cfg(NCH, chain_offset=offset, Nchains_local=nloc, seed=99, Nt_learn=(10, 40, 100000),
@@ -39,31 +39,36 @@ def _make(offset, nloc):
     return smp
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, NCH):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tamcmc_amd import sampler as S
     per = NCH // world
-    smp = _make(rank * per, per)
+    smp = _make(rank * per, per, NCH)
     swaps = S.run_sharded(smp, NIT, dist, rank, world, per)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), vars=smp.get("vars"), logL=smp.get("logL"), logPost=smp.get("logPost"),
              sigma=smp.get("sigma"), swaps=np.array([[a, int(s)] for a, s in swaps]).reshape(-1, 2))
     dist.destroy_process_group()
 
 
-def test_two_rank_sampler_equals_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("NCH", [6, 40])     # 40: the other rank's 20 chains are passed over by the generator's jump-ahead
+def test_two_rank_sampler_equals_single_process(tmp_path, NCH):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    single = _make(0, NCH)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), NCH), nprocs=2, join=True)
+    single = _make(0, NCH, NCH)
     moved, swaps = single.run(NIT)
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     for key in ("vars", "logL", "logPost", "sigma"):
         assert np.array_equal(np.concatenate([r0[key], r1[key]]), single.get(key)), key
-    # the boundary pair (2, 3) was attempted by both ranks with the same outcome, and swaps did happen
-    b0 = {tuple(r) for r in r0["swaps"] if r[0] == 2}
-    b1 = {tuple(r) for r in r1["swaps"] if r[0] == 2}
-    assert b0 == b1 and len(b0) > 0
+    # the boundary pair was attempted by both ranks with the same outcome (6 chains: and it did come up)
+    bp = NCH // 2 - 1
+    b0 = {tuple(r) for r in r0["swaps"] if r[0] == bp}
+    b1 = {tuple(r) for r in r1["swaps"] if r[0] == bp}
+    assert b0 == b1 and (len(b0) > 0 or NCH > 6)
     ref = [(int(v) // 2, int(v) % 2) for v in swaps if v >= 0]
     got = sorted({(int(a), int(sw)) for a, sw in np.concatenate([r0["swaps"], r1["swaps"]])})
     assert got == sorted(set(ref))
