@@ -34,6 +34,11 @@ def main(tag):
     for f in ("bench.json", "bench_2rank_gloo_rehearsal.json", "pytest_gpu.log", "pmc_summary.json", "hbm_traffic.json"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    # (the gloo backend greets on stdout before bench.py's line: keep the JSON line only)
+    reh = os.path.join(dst, "bench_2rank_gloo_rehearsal.json")
+    if os.path.exists(reh):
+        lines = [l for l in open(reh) if l.startswith("{")]
+        open(reh, "w").writelines(lines)
     ks = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(dst, "kernel_stats.csv"))
