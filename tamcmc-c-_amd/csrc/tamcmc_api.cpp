@@ -546,7 +546,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, d_params, c->d_wt, c->d_chain_rec, c->d_aux, c->d_noise, c->d_part,
+        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, tm_setup_balances(units, tiles, c->equal_cost, (grad ? c->cost_g : c->cost_l).pad), d_params, c->d_wt, c->d_chain_rec, c->d_aux, c->d_noise, c->d_part,
                                 c->d_gmult, c->d_gnoise, c->d_cell, c->d_thdr, c->d_hser, c->Nvars, c->d_relax, d_grad, d_logL, d_status,
                                 c->stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }

@@ -36,7 +36,7 @@ __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + 
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
 #define TM_BW_THREADS 256
-__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int cells,
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int cells, int uniform_su,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmChain *__restrict__ chain_rec,
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             // tile starts: the first one is the tile holding unit ua -- the last tile that starts at or before it (empty
             // tiles share a start with their successor and are passed over by taking the last).
             const int ua = M.imin >> TM_UNIT_SHIFT, ub = (M.imax - 1) >> TM_UNIT_SHIFT;
-            if (s_u[1] * (tiles - 1) == s_u[tiles - 1] && s_u[1] > 0) {
-                const int su = s_u[1], tA = ua / su, tB = (ub / su < tiles - 1) ? ub / su : tiles - 1;
+            if (uniform_su > 0) {
+                const int su = uniform_su, tA = ua / su, tB = (ub / su < tiles - 1) ? ub / su : tiles - 1;
                 const double *G = gmult + (((size_t)chain * tiles + tA) * nm + j) * TM_GSLOTS + sl;
                 const size_t stride = (size_t)nm * TM_GSLOTS;
 #pragma unroll 4
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     for (int k = tid; k < Nvars; k += TM_BW_THREADS) grad[(size_t)chain * Nvars + k] = s_row[k];
 }
 
-int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, int equal_cost, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise, const TmCellRec *d_cell,
                        const TmTileHdr *d_thdr, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad,
@@ -533,7 +533,9 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles, cells,
+    // tiles of equal length (su units each): the tiles a window meets follow by division; else (per-chain boundaries) by search
+    const int uniform_su = equal_cost ? 0 : (units + tiles - 1) / tiles;
+    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles, cells, uniform_su,
                        d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec), static_cast<const TmMultFull *>(d_aux), d_noise,
                        d_part, d_gmult, d_gnoise, d_cell, d_thdr, d_hser, Nvars, d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();

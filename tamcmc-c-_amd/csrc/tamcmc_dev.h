@@ -172,6 +172,16 @@ static inline int tm_tiles(int units, int grad)
 #else
 #define TM_HD
 #endif
+// Whether the setup kernel balances a chain's tiles (per-chain boundaries) or cuts tiles of equal length: the balancer
+// needs slack (tiles * TM_TILE_MAXU > units), its bound is TM_TILE_MAXU units per tile, and its tables live in LDS.
+// One predicate for the setup launcher, the setup body and the backward kernel (which finds the tiles a window meets
+// by division when they have equal length, by a search over the tile starts otherwise).
+static inline TM_HD int tm_setup_balances(int units, int tiles, int equal_cost, int max_units_per_tile)
+{
+    return (equal_cost != 0 && max_units_per_tile == TM_TILE_MAXU && tiles > 1 && tiles <= TM_ORDER_MAX && units <= TM_EQ_MAXU &&
+            (long long)tiles * TM_TILE_MAXU > units) ? 1 : 0;
+}
+
 // Equal-cost tile boundary t (0 < t < tiles) from the INCLUSIVE prefix `pre` of the unit costs (C = pre[units-1] the
 // total, cmin the cheapest unit): the smallest u in [0, units] with Q'(u) >= t/T of the total, where Q' is the prefix
 // of cost(u) + lambda and lambda >= 0 is the uniform surcharge that keeps every tile within S = TM_TILE_MAXU units:
@@ -219,7 +229,8 @@ int tm_launch_eval(const TmEvalArgs &a, int Nchains, bool grad, void *stream);
 // setup + eval in one launch; requires a.tiles == 1
 int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, bool grad, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
-int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, int equal_cost /* as given to tm_launch_setup */,
+                       const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise, const TmCellRec *d_cell,
                        const TmTileHdr *d_thdr, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad,

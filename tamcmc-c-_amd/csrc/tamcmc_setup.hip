@@ -32,9 +32,7 @@ int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, cons
 {
     if (tiles < 1 || cm.pad < 1 || (long long)tiles * cm.pad < units) return (int)hipErrorInvalidValue;   // cm.pad: units per tile at most
     const int p_doubles = (L.Nparams + 1) & ~1;
-    // the balancer needs slack (tiles * TM_TILE_MAXU > units) and its bound is TM_TILE_MAXU units per tile
-    const int eq = (equal_cost != 0 && cm.pad == TM_TILE_MAXU && tiles > 1 && tiles <= TM_ORDER_MAX && units <= TM_EQ_MAXU &&
-                    (long long)tiles * TM_TILE_MAXU > units) ? 1 : 0;
+    const int eq = tm_setup_balances(units, tiles, equal_cost, cm.pad);
     const size_t lds = (size_t)p_doubles * sizeof(double) + (eq ? (size_t)units * sizeof(int) : 0);
     hipLaunchKernelGGL(tamcmc_setup_kernel, dim3(Nchains), dim3(TM_SETUP_THREADS), lds, (hipStream_t)stream, L,
                        d_params, d_Tcoefs, d_wt, d_lx, units, cells, tiles, eq, cm, p_doubles, d_mult, d_noise, d_cell, d_thdr, d_tidx,

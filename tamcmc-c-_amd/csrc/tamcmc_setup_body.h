@@ -199,8 +199,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
     __shared__ int s_b[TM_ORDER_MAX + 2];      // tile boundaries in units (tiles <= TM_ORDER_MAX; else computed on the fly)
     __shared__ int s_tot[2];                   // total cost, cheapest unit
     const int nm = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
-    const bool eq = (equal_cost != 0) && tiles > 1 && tiles <= TM_ORDER_MAX && units <= TM_EQ_MAXU && s_pre != nullptr && cm.pad == TM_TILE_MAXU &&
-                    (long long)tiles * TM_TILE_MAXU > units;
+    const bool eq = tm_setup_balances(units, tiles, equal_cost, cm.pad) != 0 && s_pre != nullptr;
     const int su = (units + tiles - 1) / tiles;       // uniform tiles: su units each (su <= TM_TILE_MAXU by the tile count)
     if (eq) {
         // Equal-cost tiles.  (1) cost of every unit from the windows; (2) inclusive prefix sum (one wave: each lane a

@@ -12,9 +12,11 @@ from tamcmc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_random_configurations_match_the_oracle(accel_mod, orc):
+@pytest.mark.parametrize("balanced", [0, 1], ids=["equal-length-tiles", "equal-cost-tiles"])
+def test_random_configurations_match_the_oracle(accel_mod, orc, monkeypatch, balanced):
+    monkeypatch.setenv("TAMCMC_EQUAL_COST", str(balanced))     # 1: per-chain tile boundaries from the setup kernel's balancer
     ncases = int(os.environ.get("TAMCMC_FUZZ_CASES", "60"))
-    rng = np.random.default_rng(int(os.environ.get("TAMCMC_FUZZ_SEED", "1")))
+    rng = np.random.default_rng(int(os.environ.get("TAMCMC_FUZZ_SEED", "1")) + 1000 * balanced)
     worst_L = worst_M = worst_g = 0.0
     done, failures = 0, []
     fd_done, fd_max = 0, max(8, ncases // 10)
@@ -40,6 +42,15 @@ def test_random_configurations_match_the_oracle(accel_mod, orc):
             acc.set_vars(w["index_to_relax"])
             L, st, models = acc.eval_batch(P, T, model_rows=[row])
             Lg, stg, g = acc.eval_batch(P, T, grad=True)
+        g_ref = None
+        if balanced:
+            # the same batch with tiles of equal length: other tile boundaries, so other partial sums -- logL and every
+            # gradient entry must agree to rounding (the finite-difference check below only sees the few smooth cases)
+            monkeypatch.setenv("TAMCMC_EQUAL_COST", "0")
+            with accel_mod.Accel(mid, w["plength"], w["x"], y, sigma_y=sig, likelihood_case=like) as acc:
+                acc.set_vars(w["index_to_relax"])
+                _, _, g_ref = acc.eval_batch(P, T, grad=True)
+            monkeypatch.setenv("TAMCMC_EQUAL_COST", "1")
         rL, rst, rm = orc.generate_batch(mid, w["plength"], w["x"], y, P, T, sigma_y=sig, likelihood_case=like, want_models=True)
         ok = np.array_equal(st, rst) and np.array_equal(stg, rst)
         good = (rst == 0) & np.isfinite(rL)
@@ -48,6 +59,9 @@ def test_random_configurations_match_the_oracle(accel_mod, orc):
             eG = float(np.max(np.abs(Lg[good] - rL[good]) / np.abs(rL[good])))
             worst_L = max(worst_L, eL, eG)
             ok = ok and eL <= 1e-10 and eG <= 1e-10 and bool(np.all(np.isfinite(g[good])))
+            if g_ref is not None:
+                scale = np.max(np.abs(g_ref[good]), axis=1, keepdims=True)
+                ok = ok and bool(np.all(np.abs(g[good] - g_ref[good]) <= 1e-10 * np.maximum(scale, 1e-300)))
             if good[row]:
                 eM = float(np.max(np.abs(models[0] - rm[row]) / np.abs(rm[row])))
                 worst_M = max(worst_M, eM)

@@ -272,9 +272,10 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
     check_logL(res[2][0], rL)
     monkeypatch.delenv("TAMCMC_ORDER")
-    # other tile boundaries (equal length instead of equal cost; other tile counts): other partial sums, same answer to
-    # rounding; gradient against the default geometry
-    for env in (dict(TAMCMC_EQUAL_COST="0"), dict(TAMCMC_TILES="9", TAMCMC_TILES_GRAD="11"),
+    # other tile boundaries (equal cost instead of equal length; other tile counts; rank priority): other partial sums,
+    # same answer to rounding; gradient against the default geometry
+    for env in (dict(TAMCMC_EQUAL_COST="1"), dict(TAMCMC_EQUAL_COST="1", TAMCMC_TILES="33", TAMCMC_TILES_GRAD="29", TAMCMC_PRIO="1"),
+                dict(TAMCMC_TILES="9", TAMCMC_TILES_GRAD="11"),
                 dict(TAMCMC_TILES="40", TAMCMC_TILES_GRAD="59", TAMCMC_COST="10,1,1", TAMCMC_COST_GRAD="500,40,3")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -308,8 +309,9 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     assert np.all(np.isfinite(g))
 
 
-def test_equal_cost_tiles_follow_the_chain_not_the_batch(accel_mod, orc):
-    """Tile boundaries are chosen per chain from that chain's own truncation windows (tamcmc_setup_body.h): chains with
+def test_equal_cost_tiles_follow_the_chain_not_the_batch(accel_mod, orc, monkeypatch):
+    """With TAMCMC_EQUAL_COST=1 tile boundaries are chosen per chain from that chain's own truncation windows
+    (tamcmc_setup_body.h): chains with
     very different window patterns in one batch -- narrow windows (most of the grid is background only), the default,
     and windows that span the whole grid -- each give bit for bit what they give evaluated alone, and all agree with
     the oracle."""
@@ -320,6 +322,7 @@ def test_equal_cost_tiles_follow_the_chain_not_the_batch(accel_mod, orc):
     q = W.split(w)["cfg"]
     P[0:3, q] = 1.5        # trunc_c: windows of a few hundred bins
     P[6:9, q] = 10000.0    # no truncation
+    monkeypatch.setenv("TAMCMC_EQUAL_COST", "1")
     with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
         acc.set_vars(w["index_to_relax"])
         L, st = acc.eval_batch(P, T)
