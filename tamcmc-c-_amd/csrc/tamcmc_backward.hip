@@ -189,7 +189,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const int j = item / TM_GSLOTS, sl = item - j * TM_GSLOTS;
         const TmMultFull &M = auxp[j];
         double acc = 0.0;
-        if (M.status == 0 && (sl < 3 * M.ncomp || sl >= 21)) {
+        if (M.status == 0 && (sl < M.ncomp || (sl >= 7 && sl < 12) || sl >= 21)) {      // B_k, A_am, C, asymmetry sums (tamcmc_eval_body.h)
             // tiles whose units meet the window's units [ua, ub] (the multiplet is on their active lists).  Tiles of equal
             // length (the default) are found by division; per-chain boundaries (equal-cost tiles) by a search over the
             // tile starts: the first one is the tile holding unit ua -- the last tile that starts at or before it (empty
@@ -231,18 +231,28 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         const int l = M.l;
         const double W = M.W, g2 = W * W, f = M.f;
         double adj_g2 = 0.0, adj_f = 0.0, adj_W = 0.0, adj_fs = 0.0;
+        // Tile-summed partials of this multiplet (tamcmc_eval_body.h, tm_grad_unit): G[k] = sum wA d_k r_k^2 per component,
+        // G[7 + am] = sum wA (r_{l-am} + r_{l+am}) per |m| (the components +-m share their height), G[11] = sum wA
+        // sum_k hq_k r_k^2.
         // (fixed trip count + predicate: the loads of the seven components are issued together; the two chain-level
         // sums are kept in registers instead of read-modify-write cycles on LDS -- same order of additions)
         double s_eta = 0.0, s_a3 = 0.0;
         const int ncomp = M.ncomp;
+        adj_g2 = -G[11];
+#pragma unroll
+        for (int am = 0; am <= 3; am++) {
+            if (am <= l) {
+                const double A = G[7 + am];                 // d/d(hq) summed over the components l-am and l+am
+                adj_g2 += A * M.h[l + am];
+                adj_h[l + am] = A * g2;                    // d/d(h) of that pair (kept at the +m component)
+                if (am > 0) adj_h[l - am] = 0.0;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < TM_MAXM; k++) {
             if (k < ncomp) {
                 const double hq = M.h[k] * g2;
-                const double adj_hq = G[3 * k];
-                const double adj_nu = 4.0 * hq * G[3 * k + 1];
-                adj_g2 += -hq * G[3 * k + 2] + adj_hq * M.h[k];
-                adj_h[k] = adj_hq * g2;
+                const double adj_nu = 4.0 * hq * G[k];
                 const int m = k - l;
                 if (l != 0) {
                     adj_f += adj_nu * (1. + C.eta * M.Q[k]);

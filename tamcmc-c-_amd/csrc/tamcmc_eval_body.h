@@ -271,17 +271,35 @@ __device__ __forceinline__ void tm_accum_dispatch(TmMultK sm, const int shape, c
     }
 }
 
-// Backward, one unit (2 bins per thread) of one multiplet: add this thread's terms to g[].
-//   g[3m+0] = sum wA r_m, g[3m+1] = sum wA d_m r_m^2, g[3m+2] = sum wA r_m^2   (d = 2x - 2nu, r = 1/E)
-//   g[3NC..3NC+2] = sum w S, sum w S a, sum w S a x   (S = un-asymmetrised multiplet sum; zero if asym == 0)
+// Backward, one unit (2 bins per thread) of one multiplet: add this thread's terms to g[].  With d = 2x - 2nu, r = 1/E,
+// wA the weight times the asymmetry factor, L = (NC - 1) / 2, the chain rule needs (tamcmc_backward.hip):
+//   g[k]           = sum wA d_k r_k^2                      k = 0 .. NC-1   (d/d nu_k: every component has its own)
+//   g[NC + am]     = sum wA (r_{L-am} + r_{L+am})          am = 0 .. L     (d/d height: the components +-m share theirs)
+//   g[NC + L + 1]  = sum wA sum_k hq_k r_k^2                               (d/d Gamma^2: one per multiplet)
+//   g[V-3 .. V-1]  = sum w S, sum w S a, sum w S a x   (S = un-asymmetrised multiplet sum; only if asym != 0)
+// -- NC + L + 2 sums instead of 3 NC: fewer values to reduce over the workgroup per multiplet and tile.
 // edge (wave-uniform) = false: the unit lies inside the window and the grid (no test per bin).  Only the fetch of x and
 // of the weight differs between the two cases; the arithmetic exists once (two copies updating g[] behind a branch cost
 // ~40 registers in copies at the join).
+template <int NC> struct TmGradSlots {
+    static constexpr int L = (NC - 1) / 2;
+    static constexpr int A0 = NC, C = NC + L + 1, ASYM0 = NC + L + 2;
+    __device__ static constexpr int count(bool asym) { return asym ? ASYM0 + 3 : ASYM0; }
+};
+// where the compact slot v of a multiplet with NC components is kept in a gmult row (TM_GSLOTS doubles):
+// B_k at k, A_am at 7 + am, C at 11, the asymmetry sums at 21 .. 23
+template <int NC> __device__ __forceinline__ int tm_grad_store_slot(int v)
+{
+    using SL = TmGradSlots<NC>;
+    return (v < NC) ? v : (v < SL::C) ? 7 + (v - NC) : (v == SL::C) ? 11 : 21 + (v - SL::ASYM0);
+}
+
 template <int NC, bool ASYM>
 __device__ __forceinline__ void tm_grad_unit(const double (&nu2)[NC], const double (&hq)[NC], double g2, double aAh, double aB, double c2,
                                              int imin, int imax, const double *__restrict__ gx, const double *wq, int i0, int Nx,
                                              const bool edge, double (&g)[TM_GSLOTS])
 {
+    using SL = TmGradSlots<NC>;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         double x2, wk;
@@ -301,17 +319,18 @@ __device__ __forceinline__ void tm_grad_unit(const double (&nu2)[NC], const doub
             const double a = __builtin_fma(x2, aAh, aB);
             wA = wk * __builtin_fma(a, a, c2);
             const double ws = wk * Sv;
-            g[3 * NC + 0] += ws;
-            g[3 * NC + 1] = __builtin_fma(ws, a, g[3 * NC + 1]);
-            g[3 * NC + 2] = __builtin_fma(ws * a, 0.5 * x2, g[3 * NC + 2]);
+            g[SL::ASYM0 + 0] += ws;
+            g[SL::ASYM0 + 1] = __builtin_fma(ws, a, g[SL::ASYM0 + 1]);
+            g[SL::ASYM0 + 2] = __builtin_fma(ws * a, 0.5 * x2, g[SL::ASYM0 + 2]);
         }
 #pragma unroll
         for (int m = 0; m < NC; m++) {
             const double t1 = wA * r[m];
             const double t2 = t1 * r[m];
-            g[3 * m + 0] += t1;
-            g[3 * m + 1] = __builtin_fma(t2, d[m], g[3 * m + 1]);
-            g[3 * m + 2] += t2;
+            const int am = (m >= SL::L) ? m - SL::L : SL::L - m;
+            g[SL::A0 + am] += t1;
+            g[m] = __builtin_fma(t2, d[m], g[m]);
+            g[SL::C] = __builtin_fma(hq[m], t2, g[SL::C]);
         }
     }
 }
@@ -322,7 +341,7 @@ template <int NC, bool ASYM>
 __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restrict__ gx, const double *s_w,
                                              int u0, int u1, int Nx, int tid, int lane, double *s_red_row)
 {
-    constexpr int V = ASYM ? 3 * NC + 3 : 3 * NC;
+    constexpr int V = TmGradSlots<NC>::count(ASYM);
     double g[TM_GSLOTS];
     double nu2[NC], hq[NC];
 #pragma unroll
@@ -351,8 +370,7 @@ __device__ __forceinline__ void tm_grad_mult(TmMultK sm, const double *__restric
     bool valid = true;
     const int slot = TmBfly<V, 32>::slot_of(lane, valid);
     if ((lane & lowmask) == 0 && valid) {
-        const int dst = (slot < 3 * NC) ? slot : 21 + (slot - 3 * NC);
-        s_red_row[dst] = g[0];
+        s_red_row[tm_grad_store_slot<NC>(slot)] = g[0];
     }
 }
 
@@ -772,7 +790,11 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
             TmMultK sm = (TmMultK)(gm + idx);
             const int nc = shape & 255;
             double *red = s_red[(jj + 1) & 1][wave];
-            if (shape < 256 && lane == 0) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
+            if (lane == 0) {      // slots this multiplet does not write (A_am beyond its L; the asymmetry sums)
+                const int Lm = (nc - 1) >> 1;
+                for (int am = Lm + 1; am <= 3; am++) red[7 + am] = 0.0;
+                if (shape < 256) { red[21] = 0.0; red[22] = 0.0; red[23] = 0.0; }
+            }
             switch (shape) {
             case 1: tm_grad_mult<1, false>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
             case 3: tm_grad_mult<3, false>(sm, a.x2, s_w, u0, u1, a.Nx, tid, lane, red); break;
@@ -789,7 +811,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
             __syncthreads();
             if (tid < TM_GSLOTS) {
                 double t = 0.0;
-                if (tid < 3 * nc || tid >= 21) {
+                if (tid < nc || (tid >= 7 && tid < 12) || tid >= 21) {      // B_k, A_am, C, asymmetry sums (tm_grad_store_slot)
 #pragma unroll
                     for (int wv = 0; wv < TM_WAVES; wv++) t += s_red[(jj + 1) & 1][wv][tid];
                 }
