@@ -11,10 +11,10 @@ import sys
 
 
 def trimmed(src_glob, dst, keep=120):
-    files = glob.glob(src_glob)
+    files = sorted(glob.glob(src_glob), key=os.path.getmtime)      # a directory used twice holds two runs: the newest
     if not files:
         return
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(files[-1])))
     if not rows:
         return
     by = {}
@@ -39,9 +39,9 @@ def main(tag):
     if os.path.exists(reh):
         lines = [l for l in open(reh) if l.startswith("{")]
         open(reh, "w").writelines(lines)
-    ks = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+    ks = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if ks:
-        shutil.copy(ks[0], os.path.join(dst, "kernel_stats.csv"))
+        shutil.copy(ks[-1], os.path.join(dst, "kernel_stats.csv"))
     for name in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_clock", "calib_fetch", "calib_write"):
         trimmed(os.path.join(src, name, "*", "*_counter_collection.csv"), os.path.join(dst, name + ".csv"))
     hb = os.path.join(dst, "hbm_traffic.json")

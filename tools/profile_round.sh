@@ -5,6 +5,7 @@ TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+rm -rf $O/stats $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_clock $O/calib_fetch $O/calib_write     # a tag used twice: no mixing of runs
 cd $R
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
