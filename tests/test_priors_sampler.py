@@ -173,6 +173,44 @@ def test_sampler_invariants(orc):
     assert np.allclose(C0, C0.T) and np.all(np.linalg.eigvalsh(C0) > -1e-12)
 
 
+def test_sharded_loop_in_the_library_single_rank(orc):
+    """tamcmc_sampler_run_sharded with every chain owned here (no exchange callback needed) is tamcmc_sampler_run, and its
+    block buffer holds what the single-process driver records per iteration: the samples, the statistics and the
+    parallel-tempering attempts, plus running sums of the proposal parameters; it stops when the block is full; bad
+    arguments are refused."""
+    ev = lambda mid, w, y: oracle_evaluator(orc, mid, w, y)      # noqa: E731
+    ref, moved, swaps, w, y = make_run(orc, ev, n_iter=50)
+    smp, _, _, _, _ = make_run(orc, ev, n_iter=0)
+    blk = S.ShardBlock(smp, 30)
+    done, mv, sw = smp.run_sharded(50, None, block=blk, history=True)
+    assert done == 30 and blk.count() == 30                     # the block is full: gather, reset, call again
+    assert np.array_equal(mv[:30], moved[:30]) and np.array_equal(sw[:30], swaps[:30])
+    vars30, stat30, pt30 = blk.data("vars"), blk.data("stat"), blk.data("pt")
+    assert vars30.shape == (30, smp.nloc, smp.Nvars) and stat30.shape == (30, 3, smp.nloc) and pt30.shape == (30, 4)
+    assert np.array_equal(pt30[0], [0.0, -1.0, np.nan, -1.0], equal_nan=True)       # iteration 0: no attempt
+    assert np.array_equal(pt30[1:, 0], np.ones(29)) and np.array_equal(pt30[1:, 1] * 2 + pt30[1:, 3], swaps[1:30])
+    assert np.allclose(stat30[0, 2], stat30[0, 0] + stat30[0, 1])     # logPost = logL + logPrior (before any swap: after one the
+    #                                                                 reference's stale-prior quirk applies, SURVEY.md A.6-8)
+    sum_sigma = blk.data("sum_sigma")
+    blk.reset()
+    assert blk.count() == 0 and np.all(blk.data("sum_sigma") == 0.0) and np.all(sum_sigma > 0.0)
+    done2, mv2, sw2 = smp.run_sharded(20, None, block=blk, history=True)
+    assert done2 == 20 and np.array_equal(mv2, moved[30:]) and np.array_equal(sw2, swaps[30:])
+    assert np.array_equal(blk.data("vars")[-1], ref.get("vars")) and np.array_equal(smp.get("logPost"), ref.get("logPost"))
+    assert smp.iteration() == ref.iteration() == 50
+    sec, its = smp.timing()
+    assert all(v == 0.0 for v in sec.values())                   # timing is off unless asked for
+    smp.set_timing(True)
+    smp.run_sharded(5, None)
+    sec, its = smp.timing()
+    assert its == 5 and sec["proposals"] > 0.0 and sec["foreign_draws"] == 0.0 and sec["exchange"] == 0.0
+    lib = S._lib()
+    assert lib.tamcmc_sampler_run_sharded(smp._h, -1, S.C.cast(None, S.EXCHANGE_FN), None, None, None, None, None) != 0
+    other, _, _, _, _ = make_run(orc, ev, nchains=4, n_iter=0)
+    assert lib.tamcmc_sampler_run_sharded(other._h, 1, S.C.cast(None, S.EXCHANGE_FN), None, blk._h, None, None, None) != 0    # a block of another shape
+    blk.close()
+
+
 def test_pt_swap_bookkeeping(orc):
     smp, _, _, w, y = make_run(orc, lambda mid, w, y: oracle_evaluator(orc, mid, w, y), n_iter=5)
     T = smp.get("Tcoefs")
