@@ -94,3 +94,17 @@ def test_tile_geometry_partitions_the_grid():
     subprocess.run(["make", "-C", cpp, "-s", "geometry_check"], check=True)
     r = subprocess.run([os.path.join(cpp, "geometry_check")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match():
+    """`bench.py --gpus N` inside a launcher: the reported n_gpus is the process-group size, so a mismatch between
+    --gpus and WORLD_SIZE is an error (round 1 silently benchmarked one GPU and printed n_gpus = 1).  Needs no GPU:
+    the check comes before anything touches one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
