@@ -106,7 +106,7 @@ int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, i
  * RCCL on GPUs, gloo in the CPU tests; tamcmc-c-_amd/sharded.py); it returns 0 or non-zero on failure.  Processes that
  * own neither end do not communicate.  moved_hist / swap_hist as in tamcmc_sampler_run, except that an attempt this
  * process took no part in is recorded as -2.  With a block (below) the loop stops early when the block is full; *done
- * (may be NULL) receives the number of iterations performed. */
+ * (may be NULL) receives the number of iterations completed, also when the call returns an error. */
 typedef int (*tamcmc_exchange_fn)(void *user, int32_t my_chain, int32_t peer_chain, const double *send, double *recv,
                                   int32_t n_doubles);
 typedef struct tamcmc_shard_block tamcmc_shard_block;

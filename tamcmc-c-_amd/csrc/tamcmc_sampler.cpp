@@ -988,8 +988,13 @@ extern "C" int tamcmc_shard_block_create(tamcmc_shard_block **out, const tamcmc_
     if (!b) return TAMCMC_E_NOMEM;
     b->cap = capacity; b->nloc = s->nloc; b->nv = s->Nvars;
     const size_t n = (size_t)s->nloc, nv = (size_t)s->Nvars, c = (size_t)capacity;
-    b->vars.resize(c * n * nv); b->stat.resize(c * 3 * n); b->moved.resize(c * n); b->pt.resize(c * 4);
-    b->sum_sigma.assign(n, 0.0); b->sum_mu.assign(n * nv, 0.0); b->sum_covar.assign(n * nv * nv, 0.0); b->sum_vars.assign(n * nv, 0.0);
+    try {
+        b->vars.resize(c * n * nv); b->stat.resize(c * 3 * n); b->moved.resize(c * n); b->pt.resize(c * 4);
+        b->sum_sigma.assign(n, 0.0); b->sum_mu.assign(n * nv, 0.0); b->sum_covar.assign(n * nv * nv, 0.0); b->sum_vars.assign(n * nv, 0.0);
+    } catch (const std::bad_alloc &) {
+        delete b;
+        return TAMCMC_E_NOMEM;
+    }
     *out = b;
     return TAMCMC_OK;
 }
@@ -1049,7 +1054,7 @@ extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tam
     const int off = s->cfg.chain_offset, nloc = s->nloc, nrec = tamcmc_sampler_pt_record_size(s);
     std::vector<double> send((size_t)nrec), recv((size_t)nrec);
     int64_t k = 0;
-    if (done) *done = 0;
+    struct Done { int64_t *p; const int64_t &k; ~Done() { if (p) *p = k; } } report{done, k};   // also on the error returns
     for (; k < n_iter; k++) {
         if (block && block->n >= block->cap) break;                    // the caller gathers the block, resets it, calls again
         int rc = tamcmc_sampler_mh_step(s);
@@ -1083,7 +1088,6 @@ extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tam
         if (block) shard_block_record(block, s, att, Ad, r, swd);
         s->iter++;
     }
-    if (done) *done = k;
     return TAMCMC_OK;
 }
 
