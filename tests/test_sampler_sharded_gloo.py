@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-NIT = 60
 
 
 def _setup():
@@ -39,7 +38,7 @@ def _make(offset, nloc, NCH):
     return smp
 
 
-def _worker(rank, world, port, out_dir, NCH):
+def _worker(rank, world, port, out_dir, NCH, NIT):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,21 +54,30 @@ def _worker(rank, world, port, out_dir, NCH):
 import pytest
 
 
-@pytest.mark.parametrize("NCH", [6, 40])     # 40: the other rank's 20 chains are passed over by the generator's jump-ahead
-def test_two_rank_sampler_equals_single_process(tmp_path, NCH):
+@pytest.mark.parametrize("world,NCH,NIT", [
+    (2, 6, 60),        # the boundary pair comes up often
+    (2, 40, 60),       # the other rank's 20 chains are passed over by the generator's jump-ahead
+    (8, 256, 240)])    # BASELINE config C3's shape: 8 blocks of 32 chains, 7 boundary pairs among 255 (a handful of attempts
+                       # in 240 iterations), interior ranks that own neither end of most attempts
+def test_sharded_sampler_equals_single_process(tmp_path, world, NCH, NIT):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), NCH), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), NCH, NIT), nprocs=world, join=True)
     single = _make(0, NCH, NCH)
     moved, swaps = single.run(NIT)
-    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    rr = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     for key in ("vars", "logL", "logPost", "sigma"):
-        assert np.array_equal(np.concatenate([r0[key], r1[key]]), single.get(key)), key
-    # the boundary pair was attempted by both ranks with the same outcome (6 chains: and it did come up)
-    bp = NCH // 2 - 1
-    b0 = {tuple(r) for r in r0["swaps"] if r[0] == bp}
-    b1 = {tuple(r) for r in r1["swaps"] if r[0] == bp}
-    assert b0 == b1 and (len(b0) > 0 or NCH > 6)
+        assert np.array_equal(np.concatenate([r[key] for r in rr]), single.get(key)), key
+    # every pair that straddles two ranks was attempted by both owners with the same outcome
+    per = NCH // world
+    seen = 0
+    for r in range(world - 1):
+        bp = per * (r + 1) - 1
+        b0 = {tuple(v) for v in rr[r]["swaps"] if v[0] == bp}
+        b1 = {tuple(v) for v in rr[r + 1]["swaps"] if v[0] == bp}
+        assert b0 == b1
+        seen += len(b0)
+    assert seen > 0 or NCH == 40
     ref = [(int(v) // 2, int(v) % 2) for v in swaps if v >= 0]
-    got = sorted({(int(a), int(sw)) for a, sw in np.concatenate([r0["swaps"], r1["swaps"]])})
+    got = sorted({(int(a), int(sw)) for a, sw in np.concatenate([r["swaps"] for r in rr])})
     assert got == sorted(set(ref))
     assert any(sw for _, sw in ref)
