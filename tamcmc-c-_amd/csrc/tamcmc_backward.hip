@@ -35,7 +35,9 @@
 __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + (l == 1 ? 0 : l == 2 ? 2 : 5) + am; }
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
-#define TM_BW_THREADS 256
+#ifndef TM_BW_THREADS
+#define TM_BW_THREADS 512
+#endif
 __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int cells, int uniform_su,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,

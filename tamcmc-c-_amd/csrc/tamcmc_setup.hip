@@ -10,7 +10,9 @@
 #include "tamcmc_dev.h"
 #include "tamcmc_setup_body.h"
 
-#define TM_SETUP_THREADS 192   // wave 0: multiplets; wave 1: noise record + cell polynomials; wave 2: m-ratios -- concurrently
+#ifndef TM_SETUP_THREADS
+#define TM_SETUP_THREADS 512   // wave 0: multiplets; wave 1: noise record + cell polynomials; wave 2: m-ratios -- concurrently; all eight: tile lists
+#endif
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
                                                           const double *__restrict__ Tcoefs, double *__restrict__ wt,
                                                           const double *__restrict__ lx, int units, int cells, int tiles, int equal_cost,

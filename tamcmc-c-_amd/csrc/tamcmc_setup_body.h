@@ -236,42 +236,53 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         __syncthreads();
     }
     // The multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel).
-    // One WAVE per tile, one lane per multiplet: the windows come out of LDS side by side, a ballot compacts the active
-    // ones in table order, and the tile's cost comes from ballots per component count -- scalar popcounts, no exchange
-    // between lanes (a lane walking a tile's multiplets one after the other took 3 us of dependent LDS round trips).
+    // One GROUP of lanes per tile, one lane per multiplet: the windows come out of LDS side by side, a ballot compacts the
+    // active ones in table order, and the tile's cost comes from ballots per component count -- scalar popcounts, no
+    // exchange between lanes (a lane walking a tile's multiplets one after the other took 3 us of dependent LDS round
+    // trips; with three waves instead of eight the pass took 2 us longer).  A group is a whole wave, or a half / quarter
+    // of one when the chain has at most 32 / 16 multiplets: every wave then lists two / four tiles at a time.
     {
         const int lane = tid & 63, wv = tid >> 6;
         constexpr int NW = NT / 64;
-        for (int tile = wv; tile < tiles; tile += NW) {
-            int u0, u1;
-            if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
-            else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
-            if (u1 - u0 > cm.pad) { u1 = u0 + cm.pad; if (lane == 0) atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
+        const int gshift = (nm <= 16) ? 4 : (nm <= 32) ? 5 : 6;            // log2(lanes per group)
+        const int G = 1 << gshift, gpw = 64 >> gshift;                     // lanes per group, groups per wave
+        const int g = lane >> gshift, gl = lane & (G - 1);
+        const unsigned long long gmask = (G == 64) ? ~0ULL : ((1ULL << G) - 1ULL);
+        const int asym_bit = (C.asym != 0) ? 256 : 0;
+        for (int t0 = wv * gpw; t0 < tiles; t0 += NW * gpw) {              // wave-uniform trip count: the ballots below need every lane
+            const int tile = t0 + g;
+            const bool live = tile < tiles;
+            int u0 = 0, u1 = 0;
+            if (live) {
+                if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
+                else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
+                if (u1 - u0 > cm.pad) { u1 = u0 + cm.pad; if (gl == 0) atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
+            }
             const int base = u0 << TM_UNIT_SHIFT, end = u1 << TM_UNIT_SHIFT;
-            TmActive *ti = tidx + ((size_t)chain * tiles + tile) * (nm > 0 ? nm : 1);
-            const int asym_bit = (C.asym != 0) ? 256 : 0;
+            TmActive *ti = tidx + ((size_t)chain * tiles + (live ? tile : 0)) * (nm > 0 ? nm : 1);
             int nact = 0, cost = 0;
-            for (int j0 = 0; j0 < nm && u1 > u0; j0 += 64) {
-                const int j = j0 + lane;
+            for (int j0 = 0; j0 < nm; j0 += G) {
+                const int j = j0 + gl;
                 int wmin = 0, wmax = 0, nc = 0;
                 if (j < nm) { wmin = s_win[j][0]; wmax = s_win[j][1]; nc = s_win[j][2]; }
-                const bool act = (j < nm) && (wmin < end) && (wmax > base);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
+                const bool act = live && (u1 > u0) && (j < nm) && (wmin < end) && (wmax > base);
+                const int sh = g << gshift;
+                const unsigned long long m = (__builtin_amdgcn_ballot_w64(act) >> sh) & gmask;
                 if (act) {
                     TmActive A;
                     A.idx = j; A.imin = wmin; A.imax = wmax; A.shape = nc | asym_bit;
-                    ti[nact + __builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = A;
+                    ti[nact + __builtin_popcountll(m & ((1ULL << gl) - 1ULL))] = A;
                 }
-                nact += __builtin_popcountll(m);
                 // cost ~ instructions per bin of the tile's multiplets (a * ncomp + b each), from ballots per component count
-                const int n3 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && nc == 3));
-                const int n5 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && nc == 5));
-                const int n7 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && nc == 7));
+                const int n3 = __builtin_popcountll((__builtin_amdgcn_ballot_w64(act && nc == 3) >> sh) & gmask);
+                const int n5 = __builtin_popcountll((__builtin_amdgcn_ballot_w64(act && nc == 5) >> sh) & gmask);
+                const int n7 = __builtin_popcountll((__builtin_amdgcn_ballot_w64(act && nc == 7) >> sh) & gmask);
                 const int na = __builtin_popcountll(m);
+                nact += na;
                 cost += cm.a * ((na - n3 - n5 - n7) + 3 * n3 + 5 * n5 + 7 * n7) + cm.b * na;
             }
             cost = (cost + cm.c0) * 2 * (u1 - u0);
-            if (lane == 0) {
+            if (live && gl == 0) {
                 TmTileHdr H;
                 H.u0 = u0; H.u1 = u1; H.nact = nact; H.cost = cost;
                 thdr[(size_t)chain * tiles + tile] = H;
