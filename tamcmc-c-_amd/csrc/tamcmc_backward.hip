@@ -56,7 +56,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 {
     const double PI = 3.141592653589793238462643383279502884;
     const int chain = blockIdx.x, tid = threadIdx.x;
-    extern __shared__ double s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     __shared__ TmChain C;
     __shared__ double s_gn[TM_NSLOTS];
     __shared__ double s_gt[TM_NSLOTS][64 + 1];   // per-lane noise partials of wave 1 (padded: conflict-free column reads)
@@ -72,10 +72,12 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
     double *s_G = shared_adj + (size_t)nm * TM_NSHARED;        // [nm*TM_GSLOTS] tile-summed partials
     double *s_adjh = s_G + (size_t)nm * TM_GSLOTS;             // [nm*TM_MAXM]
-    int *pair_idx = reinterpret_cast<int *>(s_adjh + (size_t)nm * TM_MAXM);  // [npairs_max]
+    const int npairs_pad = (npairs_max + 3) & ~3;              // the gather reads the indices four at a time
+    int *pair_idx = reinterpret_cast<int *>(s_adjh + (size_t)nm * TM_MAXM);  // [npairs_pad], moved up to a 16-byte boundary:
+    pair_idx += (4 - (((unsigned)(uintptr_t)pair_idx >> 2) & 3)) & 3;
     // per-multiplet records: staged in LDS when they fit (coalesced copy), else read in place from global
     constexpr int AUXD = (int)(sizeof(TmMultFull) / sizeof(double));
-    int *s_u = pair_idx + ((npairs_max + 1) & ~1);             // [tiles + 1] first unit of every tile, then the end of the last
+    int *s_u = pair_idx + npairs_pad;                          // [tiles + 1] first unit of every tile, then the end of the last
     double *s_aux = reinterpret_cast<double *>(s_u + ((tiles + 2) & ~1));
     const TmMultFull *auxp = aux + (size_t)chain * nm;
     if (aux_in_lds) {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         auxp = reinterpret_cast<const TmMultFull *>(s_aux);
     }
 
-    for (int e = tid; e < npairs_max; e += TM_BW_THREADS) { pair_idx[e] = -1; pair_val[e] = 0.0; }
+    for (int e = tid; e < npairs_pad; e += TM_BW_THREADS) { pair_idx[e] = -1; if (e < npairs_max) pair_val[e] = 0.0; }
     for (int t = tid; t < tiles; t += TM_BW_THREADS) {
         const TmTileHdr H = thdr[(size_t)chain * tiles + t];
         s_u[t] = H.u0;
@@ -374,10 +376,15 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #endif
 
     // ---------------- phase 2: chain-level adjoints and noise ----------------
-    if (tid < TM_NSHARED) {
+    if (tid < 4 * TM_NSHARED) {
+        // four lanes per slot, each a contiguous quarter of the multiplets in order; the quarters are then added in a
+        // fixed order (a single lane per slot is one LDS round trip per multiplet, one after the other)
+        const int slot = tid >> 2, q = tid & 3, per = (nm + 3) >> 2;
+        const int j_lo = q * per, j_hi = (j_lo + per < nm) ? j_lo + per : nm;
         double acc = 0.0;
-        for (int j = 0; j < nm; j++) acc += shared_adj[(size_t)j * TM_NSHARED + tid];   // multiplet order
-        s_S[tid] = acc;
+        for (int j = j_lo; j < j_hi; j++) acc += shared_adj[(size_t)j * TM_NSHARED + slot];
+        const double a1 = __shfl_down(acc, 1, 4), a2 = __shfl_down(acc, 2, 4), a3 = __shfl_down(acc, 3, 4);
+        if (q == 0) s_S[slot] = ((acc + a1) + a2) + a3;
     }
     __syncthreads();
 #if defined(TM_BW_STOP) && TM_BW_STOP == 4
@@ -489,32 +496,29 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #endif
 
     // ---------------- phase 3: gather per variable, in pair order ----------------
-    // four lanes per variable, each scanning a contiguous quarter of the pairs in order; the four partial sums are
-    // then combined in a fixed order (bitwise reproducible; a single lane per variable costs one LDS latency chain
-    // over all pairs)
+    // Eight (four when there are many variables) lanes per variable, each scanning a contiguous part of the pairs in
+    // order -- the indices four at a time, a value only where the index matches (few pairs name a given variable) --
+    // and the partial sums are combined in a fixed order: bitwise reproducible, and no lane walks all the pairs.
     {
-        const int seg = tid & 3;
-        const int per = (npairs_max + 3) / 4;
-        const int e_lo = seg * per, e_hi = (e_lo + per < npairs_max) ? e_lo + per : npairs_max;
-        for (int k0 = 0; k0 < Nvars; k0 += TM_BW_THREADS / 4) {
-            const int k = k0 + (tid >> 2);
+        const int lsh = (8 * Nvars <= TM_BW_THREADS) ? 3 : 2, lpv = 1 << lsh;  // lanes per variable
+        const int seg = tid & (lpv - 1);
+        const int per = (((npairs_max + lpv - 1) / lpv) + 3) & ~3;             // pairs per lane, a multiple of four
+        const int e_lo = seg * per, e_hi = (e_lo + per < npairs_pad) ? e_lo + per : npairs_pad;
+        const int vpp = TM_BW_THREADS >> lsh;                                  // variables per pass
+        for (int k0 = 0; k0 < Nvars; k0 += vpp) {
+            const int k = k0 + (tid >> lsh);
             const int target = (k < Nvars) ? relax[k] : -2;
             double acc = 0.0;
-            for (int e0 = e_lo; e0 < e_hi; e0 += 8) {
-                int id[8];
-                double v[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const bool in = e0 + q < e_hi;
-                    const int e = in ? e0 + q : e_lo;
-                    id[q] = in ? pair_idx[e] : -1;
-                    v[q] = pair_val[e];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) acc += (id[q] == target) ? v[q] : 0.0;
+            for (int e0 = e_lo; e0 < e_hi; e0 += 4) {
+                const int4 id = *reinterpret_cast<const int4 *>(pair_idx + e0);
+                if (id.x == target) acc += pair_val[e0];
+                if (id.y == target) acc += pair_val[e0 + 1];
+                if (id.z == target) acc += pair_val[e0 + 2];
+                if (id.w == target) acc += pair_val[e0 + 3];
             }
-            const double a1 = __shfl_down(acc, 1, 4), a2 = __shfl_down(acc, 2, 4), a3 = __shfl_down(acc, 3, 4);
-            if (seg == 0 && k < Nvars) s_row[k] = ((acc + a1) + a2) + a3;
+            double tot = acc;
+            for (int q = 1; q < lpv; q++) { const double t = __shfl_down(acc, q, 8); tot += t; }   // seg 0: ((a0 + a1) + a2) + ...
+            if (seg == 0 && k < Nvars) s_row[k] = tot;
         }
     }
     // the row leaves as consecutive 8-byte stores of consecutive lanes: the caller's buffer may be host memory mapped
@@ -534,7 +538,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int
     const int npairs_max = nm * TM_NPAIR + ncp;
     if (units < 1 || cells < 1 || tiles < 1) return (int)hipErrorInvalidValue;
     size_t lds = ((size_t)L.Nparams + (size_t)Nvars) * sizeof(double) + (size_t)npairs_max * sizeof(double) +
-                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + (size_t)((npairs_max + 1) & ~1) * sizeof(int) +
+                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + 16 + (size_t)((npairs_max + 3) & ~3) * sizeof(int) +
                  (size_t)((tiles + 2) & ~1) * sizeof(int);
     const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);
     const int aux_in_lds = (lds + aux_bytes <= 100 * 1024) ? 1 : 0;

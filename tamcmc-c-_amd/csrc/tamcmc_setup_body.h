@@ -43,6 +43,9 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
 #endif
     }
     __syncthreads();
+#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 3
+    return;   // timing-only build
+#endif
     // phase 2, three waves side by side: wave 2 the m-ratios from the inclination, wave 1 the noise record and the
     // tile polynomials, wave 0 every multiplet's record up to the products with those ratios
     if (L.family != TM_FAM_GAUSS && tid >= 128) {
@@ -291,6 +294,9 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
             }
         }
     }
+#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 4
+    return;   // timing-only build
+#endif
     // launch order of this chain's tiles: costliest first (rank = number of tiles with a larger key)
     if (order != nullptr) {
         if (tiles <= TM_ORDER_MAX) {
