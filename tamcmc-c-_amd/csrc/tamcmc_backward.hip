@@ -17,6 +17,12 @@
 #include "tamcmc_dev.h"
 #include "tamcmc_derive.h"
 
+#ifdef TM_BW_TRACE   // timing-only build: cycle stamps of chain 0's phases leave through its gradient row (tools/bw_trace.py)
+#define BW_TS(i, who) do { if (tid == (who)) s_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BW_TS(i, who) do { } while (0)
+#endif
+#define NWV_ROWS (TM_BW_THREADS / 64)
 #define TM_NPAIR 12   // pairs a multiplet can emit
 #define TM_NSHARED 20 // chain-level adjoint slots per multiplet
 #define TM_NCPAIR 64  // base number of chain-level pairs (plus numax pairs for id 9)
@@ -56,6 +62,22 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 {
     const double PI = 3.141592653589793238462643383279502884;
     const int chain = blockIdx.x, tid = threadIdx.x;
+#ifdef TM_BW_TRACE
+    __shared__ unsigned long long s_ts[20];
+    if (tid < 20) s_ts[tid] = 0;
+    __syncthreads();
+#endif
+    BW_TS(0, 0);
+#ifdef TM_BW_TRACE
+    asm volatile("" :: "s"(tiles), "s"(Nvars));      // the first kernel arguments have arrived
+    BW_TS(16, 0);
+    { const double probe = params[(size_t)chain * L.Nparams]; asm volatile("" :: "v"(probe)); }   // first trip to memory
+    BW_TS(17, 0);
+    { const double probe = params[(size_t)chain * L.Nparams + 1]; asm volatile("" :: "v"(probe)); }   // same line again
+    BW_TS(18, 0);
+    { const double probe = gmult[(size_t)chain * tiles * L.n_mult * TM_GSLOTS]; asm volatile("" :: "v"(probe)); }   // another buffer
+    BW_TS(19, 0);
+#endif
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     __shared__ TmChain C;
     __shared__ double s_gn[TM_NSLOTS];
@@ -64,7 +86,6 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     const int nm = L.n_mult;
     // dynamic LDS carve-up: the chain's params row first (every later access is an LDS read)
     double *p = s_dyn;                                         // [Nparams]
-    for (int e = tid; e < L.Nparams; e += TM_BW_THREADS) p[e] = params[(size_t)chain * L.Nparams + e];
     double *s_row = s_dyn + L.Nparams;                         // [Nvars] this chain's gradient row, written out coalesced
     double *pair_val = s_row + Nvars;                          // [nm*TM_NPAIR + ncp]
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
@@ -72,29 +93,64 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
     double *s_G = shared_adj + (size_t)nm * TM_NSHARED;        // [nm*TM_GSLOTS] tile-summed partials
     double *s_adjh = s_G + (size_t)nm * TM_GSLOTS;             // [nm*TM_MAXM]
-    const int npairs_pad = (npairs_max + 3) & ~3;              // the gather reads the indices four at a time
+    const int npairs_pad = (npairs_max + 7) & ~7;              // the gather reads the pairs eight at a time
     int *pair_idx = reinterpret_cast<int *>(s_adjh + (size_t)nm * TM_MAXM);  // [npairs_pad], moved up to a 16-byte boundary:
     pair_idx += (4 - (((unsigned)(uintptr_t)pair_idx >> 2) & 3)) & 3;
     // per-multiplet records: staged in LDS when they fit (coalesced copy), else read in place from global
     constexpr int AUXD = (int)(sizeof(TmMultFull) / sizeof(double));
+    constexpr int CD = (int)(sizeof(TmChain) / sizeof(double));
     int *s_u = pair_idx + npairs_pad;                          // [tiles + 1] first unit of every tile, then the end of the last
-    double *s_aux = reinterpret_cast<double *>(s_u + ((tiles + 2) & ~1));
+    int *s_inv = s_u + ((tiles + 2) & ~1);                     // [Nparams] variable that a parameter is, or -1
+    double *s_part = reinterpret_cast<double *>(s_inv + ((L.Nparams + 1) & ~1));   // [waves][Nvars] phase 3: per-wave partial rows
+    double *s_aux = s_part + (size_t)(TM_BW_THREADS / 64) * Nvars;
     const TmMultFull *auxp = aux + (size_t)chain * nm;
-    if (aux_in_lds) {
-        for (int e = tid; e < nm * AUXD; e += TM_BW_THREADS) s_aux[e] = reinterpret_cast<const double *>(auxp)[e];
-        auxp = reinterpret_cast<const TmMultFull *>(s_aux);
-    }
+    const double *aux_src = reinterpret_cast<const double *>(auxp);
+    if (aux_in_lds) auxp = reinterpret_cast<const TmMultFull *>(s_aux);
 
-    for (int e = tid; e < npairs_pad; e += TM_BW_THREADS) { pair_idx[e] = -1; if (e < npairs_max) pair_val[e] = 0.0; }
-    for (int t = tid; t < tiles; t += TM_BW_THREADS) {
-        const TmTileHdr H = thdr[(size_t)chain * tiles + t];
-        s_u[t] = H.u0;
-        if (t == tiles - 1) s_u[tiles] = H.u1;
+    // Staging.  A trip to memory costs ~1 us here (what this kernel reads was written by other XCDs), and a wave's loads
+    // complete in order: a wave that copied the params row, then the records, then the headers paid three trips before
+    // its real work.  So waves 1 and 3 go straight to the noise partials and the likelihood (below), and the other six
+    // first ISSUE every load of the staging copies, clear the LDS tables while those are in flight, then store.
+    const int wv = tid >> 6;
+    int rv = -1, rk = 0;                                       // staging thread rk < Nvars: the parameter that variable rk is
+    if (wv != 1 && wv != 3) {
+        constexpr int NS = TM_BW_THREADS - 128;                // staging threads
+        const int sid = tid - 64 * ((wv > 1 ? 1 : 0) + (wv > 3 ? 1 : 0));
+        constexpr int KP = 2, KA = 4;
+        double rp[KP], ra[KA], rc = 0.0;
+        TmTileHdr rh;
+        rh.u0 = 0; rh.u1 = 0; rh.nact = 0; rh.cost = 0;
+#pragma unroll
+        for (int k = 0; k < KP; k++) { const int e = sid + k * NS; rp[k] = (e < L.Nparams) ? params[(size_t)chain * L.Nparams + e] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < KA; k++) { const int e = sid + k * NS; ra[k] = (aux_in_lds && e < nm * AUXD) ? aux_src[e] : 0.0; }
+        if (sid < tiles) rh = thdr[(size_t)chain * tiles + sid];
+        if (L.family != TM_FAM_GAUSS && sid < CD) rc = reinterpret_cast<const double *>(chain_rec + chain)[sid];
+        rk = sid;
+        rv = (sid < Nvars) ? relax[sid] : -1;
+        for (int e = sid; e < L.Nparams; e += NS) s_inv[e] = -1;
+        for (int e = sid; e < npairs_pad; e += NS) { pair_idx[e] = -1; if (e < npairs_max) pair_val[e] = 0.0; }   // (index padding: the gather reads up to 7 values past the table, out of the next one, and drops them)
+        for (int e = sid; e < nm * TM_NSHARED; e += NS) shared_adj[e] = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP; k++) { const int e = sid + k * NS; if (e < L.Nparams) p[e] = rp[k]; }
+        for (int e = sid + KP * NS; e < L.Nparams; e += NS) p[e] = params[(size_t)chain * L.Nparams + e];
+        if (aux_in_lds) {
+#pragma unroll
+            for (int k = 0; k < KA; k++) { const int e = sid + k * NS; if (e < nm * AUXD) s_aux[e] = ra[k]; }
+            for (int e = sid + KA * NS; e < nm * AUXD; e += NS) s_aux[e] = aux_src[e];
+        }
+        if (sid < tiles) { s_u[sid] = rh.u0; if (sid == tiles - 1) s_u[tiles] = rh.u1; }
+        for (int t = sid + NS; t < tiles; t += NS) {
+            const TmTileHdr H = thdr[(size_t)chain * tiles + t];
+            s_u[t] = H.u0;
+            if (t == tiles - 1) s_u[tiles] = H.u1;
+        }
+        if (L.family != TM_FAM_GAUSS) {
+            if (sid < CD) reinterpret_cast<double *>(&C)[sid] = rc;
+            for (int e = sid + NS; e < CD; e += NS) reinterpret_cast<double *>(&C)[e] = reinterpret_cast<const double *>(chain_rec + chain)[e];
+        }
     }
-    for (int e = tid; e < nm * TM_NSHARED; e += TM_BW_THREADS) shared_adj[e] = 0.0;
-    if (L.family != TM_FAM_GAUSS)
-        for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += TM_BW_THREADS)
-            reinterpret_cast<double *>(&C)[e] = reinterpret_cast<const double *>(chain_rec + chain)[e];
+    BW_TS(12, 0);
     // noise partials: wave 1, one lane per (tile, cell part) (stride 64).  A tile meets at most two cells and leaves one
     // set of partials per cell.  On a cell whose background was evaluated as a polynomial the eval kernel left the
     // moments m_j = sum w dl^j (slot 9: j = 0, slot j-1: j = 1..9); with profile h's series u_h = sum c_j dl^j (setup
@@ -106,32 +162,53 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         double acc[TM_NSLOTS];
 #pragma unroll
         for (int sl = 0; sl < TM_NSLOTS; sl++) acc[sl] = 0.0;
+        // Everything this lane needs is fetched in ONE round trip to memory (the partials come from other XCDs, so each
+        // trip is ~1 us): with tiles of equal length the tile's units follow from its number, so neither the cell
+        // record nor the series wait for the tile header, and the series are fetched whether or not the cell used them.
         const TmNoise *nz = noise + chain;
         const int nh = nz->nh;
+        double nzp[TM_MAXH], nzlt[TM_MAXH];
+#pragma unroll
+        for (int h = 0; h < TM_MAXH; h++) { nzp[h] = nz->p[h]; nzlt[h] = nz->lt[h]; }
+        const int units = (int)((L.Nx + TM_UNIT_BINS - 1) >> TM_UNIT_SHIFT);   // tm_units()
         for (int it = lane; it < 2 * tiles; it += 64) {
             const int t = it >> 1, part = it & 1;
-            const TmTileHdr H = thdr[(size_t)chain * tiles + t];
-            if (H.u1 <= H.u0) continue;
-            const int ce = (H.u0 >> TM_CELL_SHIFT) + part;
-            if (ce > ((H.u1 - 1) >> TM_CELL_SHIFT)) continue;          // the tile lies in one cell: no second part
+            int u0, u1;
+            if (uniform_su > 0) {      // what the setup kernel wrote into the header (tamcmc_setup_body.h)
+                u0 = t * uniform_su; u1 = u0 + uniform_su;
+                if (u0 > units) u0 = units;
+                if (u1 > units) u1 = units;
+            } else {
+                const TmTileHdr H = thdr[(size_t)chain * tiles + t];
+                u0 = H.u0; u1 = H.u1;
+            }
+            if (u1 <= u0) continue;
+            const int ce = (u0 >> TM_CELL_SHIFT) + part;
+            if (ce > ((u1 - 1) >> TM_CELL_SHIFT)) continue;          // the tile lies in one cell: no second part
             const double *G = gnoise + (((size_t)chain * tiles + t) * 2 + part) * TM_NSLOTS;
             double g[TM_NSLOTS];
 #pragma unroll
             for (int sl = 0; sl < TM_NSLOTS; sl++) g[sl] = G[sl];
             const TmCellRec *R = cell + (size_t)chain * cells + ce;
-            if (nh > 0 && R->npoly != 0) {
+            const int npoly = R->npoly;
+            const double lxc = R->lxc;
+            double cs[TM_MAXH][TM_HSER];
+#pragma unroll
+            for (int h = 0; h < TM_MAXH; h++)
+#pragma unroll
+                for (int j = 0; j < TM_HSER; j++) cs[h][j] = hser[(((size_t)chain * cells + ce) * TM_MAXH + h) * TM_HSER + j];
+            if (nh > 0 && npoly != 0) {
                 double m[TM_HSER];
                 m[0] = g[3 * TM_MAXH];
 #pragma unroll
                 for (int j = 1; j < TM_HSER; j++) m[j] = g[j - 1];
 #pragma unroll
                 for (int sl = 0; sl < 3 * TM_MAXH; sl++) g[sl] = 0.0;
-                const double lxc = R->lxc;
 #pragma unroll
                 for (int h = 0; h < TM_MAXH; h++) {
                     if (h < nh) {
-                        const double *c = hser + (((size_t)chain * cells + ce) * TM_MAXH + h) * TM_HSER;
-                        const double ip = -1.0 / nz->p[h];
+                        const double *c = cs[h];
+                        const double ip = -1.0 / nzp[h];
                         double k0 = 0.0, k1 = 0.0, k2 = 0.0;
 #pragma unroll
                         for (int j = TM_PDEG; j >= 0; j--) {
@@ -142,7 +219,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                         }
                         g[3 * h] = k0;
                         g[3 * h + 1] = k1;
-                        g[3 * h + 2] = __builtin_fma(nz->lt[h] + lxc, k1, k2);
+                        g[3 * h + 2] = __builtin_fma(nzlt[h] + lxc, k1, k2);
                     }
                 }
             }
@@ -162,10 +239,13 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         tsum += __shfl_xor(tsum, 2, 64);
         if (part == 0) s_gn[sl] = tsum;
     }
+    BW_TS(13, 64);
     // finalize (same arithmetic and order as the likelihood-only path's in-launch finalize): wave 3
-    if (tid >= 192) {
+    if (wv == 3) {
         const int lane = tid - 192;
         const double *pp = part + (size_t)chain * tiles * 4;      // per tile: {S1, mantissa product, exponent sum, -}
+        const double Tc = Tcoefs[2 * chain];                      // {T, wscale} pairs written by the setup kernel
+        const int st0 = noise[chain].status;                      // (both fetched together with the partials)
         double s1 = 0.0, s2 = 0.0;
         for (int t = lane; t < tiles; t += 64) {
             s1 += pp[4 * t];
@@ -174,15 +254,23 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
         if (lane == 0) {
             double f = (L.likelihood_case == 0) ? -L.like_p * (s1 + s2) : -s1;
-            f = f / Tcoefs[2 * chain];      // {T, wscale} pairs written by the setup kernel
-            int st = noise[chain].status;
+            f = f / Tc;
+            int st = st0;
             if (st != 0) f = __builtin_nan("");
             else if (!(f == f)) st = 1;
             logL[chain] = f;
             if (status) status[chain] = st;
         }
     }
+    BW_TS(14, 192);
+    BW_TS(15, 0);
     __syncthreads();
+    if (rv >= 0 && rv < L.Nparams) s_inv[rv] = rk;             // inverse of index_to_relax (the clears are behind the barrier)
+    for (int k = TM_BW_THREADS - 128 + tid; k < Nvars; k += TM_BW_THREADS) {   // more variables than staging threads
+        const int r = relax[k];
+        if (r >= 0 && r < L.Nparams) s_inv[r] = k;
+    }
+    BW_TS(1, 0);
 #if defined(TM_BW_STOP) && TM_BW_STOP == 1
     return;   // timing-only build
 #endif
@@ -219,6 +307,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         s_G[item] = acc;
     }
     __syncthreads();
+    BW_TS(2, 0);
 #if defined(TM_BW_STOP) && TM_BW_STOP == 2
     return;   // timing-only build
 #endif
@@ -371,6 +460,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         pi[np] = M.idx_f; pv[np] = adj_f; np++;
     }
     __syncthreads();
+    BW_TS(3, 0);
 #if defined(TM_BW_STOP) && TM_BW_STOP == 3
     return;   // timing-only build
 #endif
@@ -387,9 +477,12 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         if (q == 0) s_S[slot] = ((acc + a1) + a2) + a3;
     }
     __syncthreads();
+    BW_TS(4, 0);
 #if defined(TM_BW_STOP) && TM_BW_STOP == 4
     return;   // timing-only build
 #endif
+    BW_TS(5, 0);
+    BW_TS(10, 64);
     if (tid == 0) {
         int *pi = pair_idx + nm * TM_NPAIR;
         double *pv = pair_val + nm * TM_NPAIR;
@@ -456,6 +549,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                 for (int l = 1; l <= L.lmax; l++) { pi[np] = L.Nmax + l - 1; pv[np] = tm_sign(pVv[l - 1]) * adj_V[l]; np++; }
         }
     }
+    BW_TS(6, 0);
     if (tid == 64) {   // noise terms on another wave, concurrently with the chain-level work of thread 0
         int *pi = pair_idx + nm * TM_NPAIR + (ncp - 16);
         double *pv = pair_val + nm * TM_NPAIR + (ncp - 16);
@@ -490,41 +584,71 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             pi[np] = 1; pv[np] = 0.5 * gA * E2 / (s2 * s2) * 2.0 * p[1]; np++;
         }
     }
+    BW_TS(11, 64);
     __syncthreads();
+    BW_TS(7, 0);
 #if defined(TM_BW_STOP) && TM_BW_STOP == 5
     return;   // timing-only build
 #endif
 
     // ---------------- phase 3: gather per variable, in pair order ----------------
-    // Eight (four when there are many variables) lanes per variable, each scanning a contiguous part of the pairs in
-    // order -- the indices four at a time, a value only where the index matches (few pairs name a given variable) --
-    // and the partial sums are combined in a fixed order: bitwise reproducible, and no lane walks all the pairs.
+    // Every wave takes a contiguous run of 64-pair chunks; a lane stands for a pair when it reads (the variable its
+    // parameter is, through the inverse map) and for a variable when it sums: one ballot per variable tells lane k which
+    // of the chunk's pairs are its own, and it adds those values in pair order.  The waves' partial rows are then added
+    // in wave order, so a variable's pairs are summed in pair order whatever their number.  (Comparing every variable
+    // with every pair -- 44 x 316 here -- kept the LDS pipe busy for 2.7 us; a value read only on a match inside such
+    // a scan is a round trip in a divergent branch.)
     {
-        const int lsh = (8 * Nvars <= TM_BW_THREADS) ? 3 : 2, lpv = 1 << lsh;  // lanes per variable
-        const int seg = tid & (lpv - 1);
-        const int per = (((npairs_max + lpv - 1) / lpv) + 3) & ~3;             // pairs per lane, a multiple of four
-        const int e_lo = seg * per, e_hi = (e_lo + per < npairs_pad) ? e_lo + per : npairs_pad;
-        const int vpp = TM_BW_THREADS >> lsh;                                  // variables per pass
-        for (int k0 = 0; k0 < Nvars; k0 += vpp) {
-            const int k = k0 + (tid >> lsh);
-            const int target = (k < Nvars) ? relax[k] : -2;
+        constexpr int NWV = TM_BW_THREADS / 64;
+        const int lane = tid & 63;
+        const int nchunks = (npairs_max + 63) >> 6;
+        const int cpw = (nchunks + NWV - 1) / NWV;
+        const int c_lo = wv * cpw, c_hi = (c_lo + cpw < nchunks) ? c_lo + cpw : nchunks;
+        for (int k0 = 0; k0 < Nvars; k0 += 64) {
+            const int nk = (Nvars - k0 < 64) ? Nvars - k0 : 64;
             double acc = 0.0;
-            for (int e0 = e_lo; e0 < e_hi; e0 += 4) {
-                const int4 id = *reinterpret_cast<const int4 *>(pair_idx + e0);
-                if (id.x == target) acc += pair_val[e0];
-                if (id.y == target) acc += pair_val[e0 + 1];
-                if (id.z == target) acc += pair_val[e0 + 2];
-                if (id.w == target) acc += pair_val[e0 + 3];
+            for (int c = c_lo; c < c_hi; c++) {
+                const int e = (c << 6) + lane;
+                const int idx = (e < npairs_max) ? pair_idx[e] : -1;
+                const int ke = (idx >= 0) ? s_inv[idx] - k0 : -1;          // this pair's variable, relative to the block of 64
+                unsigned lo = 0, hi = 0;
+                for (int kk = 0; kk < nk; kk += 4) {       // four at a time (past nk: no pair matches, the lanes get empty sets)
+                    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(ke == kk), m1 = __builtin_amdgcn_ballot_w64(ke == kk + 1);
+                    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(ke == kk + 2), m3 = __builtin_amdgcn_ballot_w64(ke == kk + 3);
+                    if (lane == kk) { lo = (unsigned)m0; hi = (unsigned)(m0 >> 32); }
+                    if (lane == kk + 1) { lo = (unsigned)m1; hi = (unsigned)(m1 >> 32); }
+                    if (lane == kk + 2) { lo = (unsigned)m2; hi = (unsigned)(m2 >> 32); }
+                    if (lane == kk + 3) { lo = (unsigned)m3; hi = (unsigned)(m3 >> 32); }
+                }
+                unsigned long long mine = ((unsigned long long)hi << 32) | lo;
+                const double *pvc = pair_val + (c << 6);
+                while (mine != 0) {
+                    acc += pvc[__builtin_ctzll(mine)];
+                    mine &= mine - 1;
+                }
             }
-            double tot = acc;
-            for (int q = 1; q < lpv; q++) { const double t = __shfl_down(acc, q, 8); tot += t; }   // seg 0: ((a0 + a1) + a2) + ...
-            if (seg == 0 && k < Nvars) s_row[k] = tot;
+            if (lane < nk) s_part[(size_t)wv * Nvars + k0 + lane] = acc;
         }
     }
-    // the row leaves as consecutive 8-byte stores of consecutive lanes: the caller's buffer may be host memory mapped
-    // over PCIe, where a scattered store is a transaction of its own
+    BW_TS(8, 0);
     __syncthreads();
+    for (int k = tid; k < Nvars; k += TM_BW_THREADS) {
+        double v[NWV_ROWS];
+#pragma unroll
+        for (int w = 0; w < NWV_ROWS; w++) v[w] = s_part[(size_t)w * Nvars + k];
+        double tot = v[0];
+#pragma unroll
+        for (int w = 1; w < NWV_ROWS; w++) tot += v[w];
+        s_row[k] = tot;
+    }
+    // the row leaves as consecutive 8-byte stores of consecutive lanes: the caller's buffer may be host memory mapped
+    // over PCIe, where a scattered store is a transaction of its own (each thread stores what it has just summed)
+    BW_TS(9, 0);
     for (int k = tid; k < Nvars; k += TM_BW_THREADS) grad[(size_t)chain * Nvars + k] = s_row[k];
+#ifdef TM_BW_TRACE
+    __syncthreads();
+    if (tid < 20 && tid < Nvars) grad[(size_t)chain * Nvars + tid] = (double)(long long)(s_ts[tid] - s_ts[0]);
+#endif
 }
 
 int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, int equal_cost, const double *d_params,
@@ -538,8 +662,9 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int
     const int npairs_max = nm * TM_NPAIR + ncp;
     if (units < 1 || cells < 1 || tiles < 1) return (int)hipErrorInvalidValue;
     size_t lds = ((size_t)L.Nparams + (size_t)Nvars) * sizeof(double) + (size_t)npairs_max * sizeof(double) +
-                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + 16 + (size_t)((npairs_max + 3) & ~3) * sizeof(int) +
-                 (size_t)((tiles + 2) & ~1) * sizeof(int);
+                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + 16 + (size_t)((npairs_max + 7) & ~7) * sizeof(int) +
+                 (size_t)((tiles + 2) & ~1) * sizeof(int) + (size_t)((L.Nparams + 1) & ~1) * sizeof(int) +
+                 (size_t)(TM_BW_THREADS / 64) * Nvars * sizeof(double);
     const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);
     const int aux_in_lds = (lds + aux_bytes <= 100 * 1024) ? 1 : 0;
     if (aux_in_lds) lds += aux_bytes;
