@@ -41,6 +41,152 @@
 __device__ __forceinline__ int tm_ratio_slot(int l, int am) { return SL_RATIO + (l == 1 ? 0 : l == 2 ? 2 : 5) + am; }
 __device__ __forceinline__ double tm_sign(double v) { return (v < 0.0) ? -1.0 : 1.0; }
 
+// Chain rule of one multiplet: from its tile-summed partials G to (parameter, value) pairs and to its share of the
+// chain-level adjoints.  One lane runs this alone, so what it costs is LDS round trips: every operand is declared free
+// of aliases (the tables are disjoint parts of the workgroup's LDS), which lets the loads go out ahead of the stores
+// instead of one by one behind them, and the heights' adjoints stay in registers.
+__device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__restrict__ Cp, const TmMultFull *__restrict__ Mp,
+                                           const double *__restrict__ G, const double *__restrict__ p, double *__restrict__ sh,
+                                           int *__restrict__ pi, double *__restrict__ pv)
+{
+    const double PI = 3.141592653589793238462643383279502884;
+    const TmChain &C = *Cp;
+    const TmMultFull &M = *Mp;
+    int np = 0;
+    if (M.status != 0) return;
+    const int l = M.l;
+    const double W = M.W, g2 = W * W, f = M.f;
+    double adj_f = 0.0, adj_W = 0.0, adj_fs = 0.0;
+    // Tile-summed partials of this multiplet (tamcmc_eval_body.h, tm_grad_unit): G[k] = sum wA d_k r_k^2 per component,
+    // G[7 + am] = sum wA (r_{l-am} + r_{l+am}) per |m| (the components +-m share their height), G[11] = sum wA
+    // sum_k hq_k r_k^2.
+    double s_eta = 0.0, s_a3 = 0.0;
+    const int ncomp = M.ncomp;
+    double adj_g2 = -G[11];
+    double ah[4];                       // d/d(h) of the pair of components +-am (kept at the +m component), am = 0..l
+#pragma unroll
+    for (int am = 0; am <= 3; am++) {
+        ah[am] = 0.0;
+        if (am <= l) {
+            const double A = G[7 + am];                 // d/d(hq) summed over the components l-am and l+am
+            adj_g2 += A * M.h[l + am];
+            ah[am] = A * g2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TM_MAXM; k++) {
+        if (k < ncomp) {
+            const double hq = M.h[k] * g2;
+            const double adj_nu = 4.0 * hq * G[k];
+            const int m = k - l;
+            if (l != 0) {
+                adj_f += adj_nu * (1. + C.eta * M.Q[k]);
+                s_eta += adj_nu * f * M.Q[k];
+                adj_fs += adj_nu * (double)m;
+                s_a3 += adj_nu * M.c[k];
+            } else {
+                adj_f += adj_nu;
+            }
+        }
+    }
+    if (l != 0) { sh[SL_ETA] = s_eta; sh[SL_A3] = s_a3; }      // the slots were zero
+    adj_W += 2.0 * W * adj_g2;
+    if (C.asym != 0) {
+        const double al = C.asym;
+        const double cc = 0.5 * W * al / f, c2 = cc * cc;
+        const double C0 = G[21], C1 = G[22], C2 = G[23];
+        sh[SL_ASYM] += 2.0 * (C2 / f - C1) + (2.0 * c2 / al) * C0;
+        adj_W += (2.0 * c2 / W) * C0;
+        adj_f += -2.0 * al / (f * f) * C2 - (2.0 * c2 / f) * C0;
+    }
+    // splitting
+    if (L.variant == 1) {
+        double a1s = 0.0, a2s = 0.0;
+        if (l == 1) a1s = adj_fs;
+        if (l == 2) a2s = adj_fs;
+        if (l == 3) { a1s = 0.5 * adj_fs; a2s = 0.5 * adj_fs; }
+        if (L.model_case == 6) { sh[SL_FS1] += a1s; sh[SL_FS2] += a2s; }
+        if (L.model_case == 7) { pi[np] = L.s + 6 + M.n; pv[np] = tm_sign(p[L.s + 6 + M.n]) * (a1s + a2s); np++; }
+        if (L.model_case == 8) {
+            pi[np] = L.s + 6 + M.n; pv[np] = tm_sign(p[L.s + 6 + M.n]) * a1s; np++;
+            pi[np] = L.s + 6 + L.Nmax + M.n; pv[np] = tm_sign(p[L.s + 6 + L.Nmax + M.n]) * a2s; np++;
+        }
+    } else {
+        sh[SL_A1] += adj_fs;
+    }
+    // heights
+    const double piW = PI * W;
+    if (L.variant != 2) {
+        // components below l carry no adjoint of their own: the sum over the components reduces to the +m ones
+        double adj_H = 0.0;
+#pragma unroll
+        for (int am = 0; am <= 3; am++)
+            if (am <= l) adj_H += ah[am] * C.ratios[l][l + am];
+        // ratio slot |m| collects the pair's adjoint; the slots were zero
+#pragma unroll
+        for (int am = 0; am <= 3; am++)
+            if (am <= l && l > 0) sh[tm_ratio_slot(l, am)] = ah[am] * M.H;
+        const double pn = p[M.idx_h];
+        const bool plain = (l == 0 || L.family == TM_FAM_LOCAL);
+        const double Vl = plain ? 1.0 : C.Vl[l];
+        const double scale = C.do_amp ? 1.0 / piW : 1.0;
+        pi[np] = M.idx_h; pv[np] = tm_sign(pn) * scale * Vl * adj_H; np++;
+        if (!plain) sh[SL_V + l - 1] += fabs(pn) * scale * adj_H;
+        if (C.do_amp) adj_W += -M.H / W * adj_H;
+    } else {
+        const double scale = C.do_amp ? 1.0 / piW : 1.0;
+#pragma unroll
+        for (int am = 0; am <= 3; am++) {
+            if (am <= l) {
+                const double a = ah[am];
+                pi[np] = M.idx_h + am; pv[np] = tm_sign(p[M.idx_h + am]) * scale * a; np++;
+                if (C.do_amp) adj_W += -M.h[l + am] / W * a;
+            }
+        }
+    }
+    // width
+    if (M.width_kind == 0) {
+        pi[np] = M.idx_w0; pv[np] = tm_sign(M.Wraw) * adj_W; np++;
+    } else if (M.width_kind == 1) {
+        const double adj_v = tm_sign(M.Wraw) * adj_W;
+        const double F0 = p[M.idx_F0], F1 = p[M.idx_F1];
+        const double t = (f - F0) / (F1 - F0), a = M.slope;
+        adj_f += a * adj_v;
+        pi[np] = M.idx_w0; pv[np] = (1.0 - t) * adj_v; np++;
+        pi[np] = M.idx_w1; pv[np] = t * adj_v; np++;
+        pi[np] = M.idx_F0; pv[np] = a * (t - 1.0) * adj_v; np++;
+        pi[np] = M.idx_F1; pv[np] = -a * t * adj_v; np++;
+    } else {
+        const int w = L.w;
+        const double adj_ln = W * adj_W;
+        if (M.width_kind == 2) {
+            const double numax = C.numax;
+            const double N = log(f / p[w + 0]), D = log(p[w + 3] / numax), A = log(p[w + 4]);
+            const double e = 2. * N / D, q1 = 1. + e * e;
+            const double dLde = 2.0 * A * e / (q1 * q1);
+            pi[np] = w + 1; pv[np] = adj_ln * log(f / numax); np++;
+            pi[np] = w + 2; pv[np] = adj_ln / p[w + 2]; np++;
+            pi[np] = w + 4; pv[np] = -adj_ln / (p[w + 4] * q1); np++;
+            pi[np] = w + 0; pv[np] = adj_ln * dLde * (-2.0 / (p[w + 0] * D)); np++;
+            pi[np] = w + 3; pv[np] = adj_ln * dLde * (-2.0 * N / (D * D * p[w + 3])); np++;
+            adj_f += adj_ln * (p[w + 1] / f + dLde * 2.0 / (f * D));
+            sh[SL_NUMAX] += adj_ln * (-p[w + 1] / numax + dLde * 2.0 * N / (D * D * numax));
+        } else {
+            const double N = log(f / p[w + 1]), D = log(p[w + 4] / p[w + 0]), A = log(p[w + 5]);
+            const double e = 2. * N / D, q1 = 1. + e * e;
+            const double dLde = 2.0 * A * e / (q1 * q1);
+            pi[np] = w + 2; pv[np] = adj_ln * log(f / p[w + 0]); np++;
+            pi[np] = w + 3; pv[np] = adj_ln / p[w + 3]; np++;
+            pi[np] = w + 5; pv[np] = -adj_ln / (p[w + 5] * q1); np++;
+            pi[np] = w + 1; pv[np] = adj_ln * dLde * (-2.0 / (p[w + 1] * D)); np++;
+            pi[np] = w + 4; pv[np] = adj_ln * dLde * (-2.0 * N / (D * D * p[w + 4])); np++;
+            pi[np] = w + 0; pv[np] = adj_ln * (-p[w + 2] / p[w + 0] + dLde * 2.0 * N / (D * D * p[w + 0])); np++;
+            adj_f += adj_ln * (p[w + 2] / f + dLde * 2.0 / (f * D));
+        }
+    }
+    pi[np] = M.idx_f; pv[np] = adj_f; np++;
+}
+
 #ifndef TM_BW_THREADS
 #define TM_BW_THREADS 512
 #endif
@@ -92,9 +238,8 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     const int npairs_max = nm * TM_NPAIR + ncp;
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
     double *s_G = shared_adj + (size_t)nm * TM_NSHARED;        // [nm*TM_GSLOTS] tile-summed partials
-    double *s_adjh = s_G + (size_t)nm * TM_GSLOTS;             // [nm*TM_MAXM]
     const int npairs_pad = (npairs_max + 7) & ~7;              // the gather reads the pairs eight at a time
-    int *pair_idx = reinterpret_cast<int *>(s_adjh + (size_t)nm * TM_MAXM);  // [npairs_pad], moved up to a 16-byte boundary:
+    int *pair_idx = reinterpret_cast<int *>(s_G + (size_t)nm * TM_GSLOTS);  // [npairs_pad], moved up to a 16-byte boundary:
     pair_idx += (4 - (((unsigned)(uintptr_t)pair_idx >> 2) & 3)) & 3;
     // per-multiplet records: staged in LDS when they fit (coalesced copy), else read in place from global
     constexpr int AUXD = (int)(sizeof(TmMultFull) / sizeof(double));
@@ -311,154 +456,10 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #if defined(TM_BW_STOP) && TM_BW_STOP == 2
     return;   // timing-only build
 #endif
-    // phase 1b: chain rule, one thread per multiplet (records read in place: no private arrays -> no scratch)
-    for (int j = tid; j < nm; j += TM_BW_THREADS) {
-        const TmMultFull &M = auxp[j];
-        double *sh = shared_adj + (size_t)j * TM_NSHARED;
-        int *pi = pair_idx + j * TM_NPAIR;
-        double *pv = pair_val + j * TM_NPAIR;
-        int np = 0;
-        if (M.status != 0) continue;
-        const double *G = s_G + (size_t)j * TM_GSLOTS;
-        double *adj_h = s_adjh + (size_t)j * TM_MAXM;
-        const int l = M.l;
-        const double W = M.W, g2 = W * W, f = M.f;
-        double adj_g2 = 0.0, adj_f = 0.0, adj_W = 0.0, adj_fs = 0.0;
-        // Tile-summed partials of this multiplet (tamcmc_eval_body.h, tm_grad_unit): G[k] = sum wA d_k r_k^2 per component,
-        // G[7 + am] = sum wA (r_{l-am} + r_{l+am}) per |m| (the components +-m share their height), G[11] = sum wA
-        // sum_k hq_k r_k^2.
-        // (fixed trip count + predicate: the loads of the seven components are issued together; the two chain-level
-        // sums are kept in registers instead of read-modify-write cycles on LDS -- same order of additions)
-        double s_eta = 0.0, s_a3 = 0.0;
-        const int ncomp = M.ncomp;
-        adj_g2 = -G[11];
-#pragma unroll
-        for (int am = 0; am <= 3; am++) {
-            if (am <= l) {
-                const double A = G[7 + am];                 // d/d(hq) summed over the components l-am and l+am
-                adj_g2 += A * M.h[l + am];
-                adj_h[l + am] = A * g2;                    // d/d(h) of that pair (kept at the +m component)
-                if (am > 0) adj_h[l - am] = 0.0;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TM_MAXM; k++) {
-            if (k < ncomp) {
-                const double hq = M.h[k] * g2;
-                const double adj_nu = 4.0 * hq * G[k];
-                const int m = k - l;
-                if (l != 0) {
-                    adj_f += adj_nu * (1. + C.eta * M.Q[k]);
-                    s_eta += adj_nu * f * M.Q[k];
-                    adj_fs += adj_nu * (double)m;
-                    s_a3 += adj_nu * M.c[k];
-                } else {
-                    adj_f += adj_nu;
-                }
-            }
-        }
-        if (l != 0) { sh[SL_ETA] = s_eta; sh[SL_A3] = s_a3; }      // the slots were zero
-        adj_W += 2.0 * W * adj_g2;
-        if (C.asym != 0) {
-            const double al = C.asym;
-            const double cc = 0.5 * W * al / f, c2 = cc * cc;
-            const double C0 = G[21], C1 = G[22], C2 = G[23];
-            sh[SL_ASYM] += 2.0 * (C2 / f - C1) + (2.0 * c2 / al) * C0;
-            adj_W += (2.0 * c2 / W) * C0;
-            adj_f += -2.0 * al / (f * f) * C2 - (2.0 * c2 / f) * C0;
-        }
-        // splitting
-        if (L.variant == 1) {
-            double a1s = 0.0, a2s = 0.0;
-            if (l == 1) a1s = adj_fs;
-            if (l == 2) a2s = adj_fs;
-            if (l == 3) { a1s = 0.5 * adj_fs; a2s = 0.5 * adj_fs; }
-            if (L.model_case == 6) { sh[SL_FS1] += a1s; sh[SL_FS2] += a2s; }
-            if (L.model_case == 7) { pi[np] = L.s + 6 + M.n; pv[np] = tm_sign(p[L.s + 6 + M.n]) * (a1s + a2s); np++; }
-            if (L.model_case == 8) {
-                pi[np] = L.s + 6 + M.n; pv[np] = tm_sign(p[L.s + 6 + M.n]) * a1s; np++;
-                pi[np] = L.s + 6 + L.Nmax + M.n; pv[np] = tm_sign(p[L.s + 6 + L.Nmax + M.n]) * a2s; np++;
-            }
-        } else {
-            sh[SL_A1] += adj_fs;
-        }
-        // heights
-        const double piW = PI * W;
-        if (L.variant != 2) {
-            double adj_H = 0.0;
-#pragma unroll
-            for (int k = 0; k < TM_MAXM; k++)
-                if (k < ncomp) adj_H += adj_h[k] * C.ratios[l][k];
-            // ratio slot |m| collects component l-|m|, then l+|m| (the order of the component loop); the slots were zero
-            for (int am = 0; am <= l && l > 0; am++) {
-                double r = adj_h[l - am] * M.H;
-                if (am > 0) r += adj_h[l + am] * M.H;
-                sh[tm_ratio_slot(l, am)] = r;
-            }
-            const double pn = p[M.idx_h];
-            const bool plain = (l == 0 || L.family == TM_FAM_LOCAL);
-            const double Vl = plain ? 1.0 : C.Vl[l];
-            const double scale = C.do_amp ? 1.0 / piW : 1.0;
-            pi[np] = M.idx_h; pv[np] = tm_sign(pn) * scale * Vl * adj_H; np++;
-            if (!plain) sh[SL_V + l - 1] += fabs(pn) * scale * adj_H;
-            if (C.do_amp) adj_W += -M.H / W * adj_H;
-        } else {
-            if (l == 0) {
-                const double scale = C.do_amp ? 1.0 / piW : 1.0;
-                pi[np] = M.idx_h; pv[np] = tm_sign(p[M.idx_h]) * scale * adj_h[0]; np++;
-                if (C.do_amp) adj_W += -M.h[0] / W * adj_h[0];
-            } else {
-                const double scale = C.do_amp ? 1.0 / piW : 1.0;
-                for (int am = 0; am <= l; am++) {
-                    double a = adj_h[l + am];
-                    if (am > 0) a += adj_h[l - am];
-                    pi[np] = M.idx_h + am; pv[np] = tm_sign(p[M.idx_h + am]) * scale * a; np++;
-                    if (C.do_amp) adj_W += -M.h[l + am] / W * a;
-                }
-            }
-        }
-        // width
-        if (M.width_kind == 0) {
-            pi[np] = M.idx_w0; pv[np] = tm_sign(M.Wraw) * adj_W; np++;
-        } else if (M.width_kind == 1) {
-            const double adj_v = tm_sign(M.Wraw) * adj_W;
-            const double F0 = p[M.idx_F0], F1 = p[M.idx_F1];
-            const double t = (f - F0) / (F1 - F0), a = M.slope;
-            adj_f += a * adj_v;
-            pi[np] = M.idx_w0; pv[np] = (1.0 - t) * adj_v; np++;
-            pi[np] = M.idx_w1; pv[np] = t * adj_v; np++;
-            pi[np] = M.idx_F0; pv[np] = a * (t - 1.0) * adj_v; np++;
-            pi[np] = M.idx_F1; pv[np] = -a * t * adj_v; np++;
-        } else {
-            const int w = L.w;
-            const double adj_ln = W * adj_W;
-            if (M.width_kind == 2) {
-                const double numax = C.numax;
-                const double N = log(f / p[w + 0]), D = log(p[w + 3] / numax), A = log(p[w + 4]);
-                const double e = 2. * N / D, q1 = 1. + e * e;
-                const double dLde = 2.0 * A * e / (q1 * q1);
-                pi[np] = w + 1; pv[np] = adj_ln * log(f / numax); np++;
-                pi[np] = w + 2; pv[np] = adj_ln / p[w + 2]; np++;
-                pi[np] = w + 4; pv[np] = -adj_ln / (p[w + 4] * q1); np++;
-                pi[np] = w + 0; pv[np] = adj_ln * dLde * (-2.0 / (p[w + 0] * D)); np++;
-                pi[np] = w + 3; pv[np] = adj_ln * dLde * (-2.0 * N / (D * D * p[w + 3])); np++;
-                adj_f += adj_ln * (p[w + 1] / f + dLde * 2.0 / (f * D));
-                sh[SL_NUMAX] += adj_ln * (-p[w + 1] / numax + dLde * 2.0 * N / (D * D * numax));
-            } else {
-                const double N = log(f / p[w + 1]), D = log(p[w + 4] / p[w + 0]), A = log(p[w + 5]);
-                const double e = 2. * N / D, q1 = 1. + e * e;
-                const double dLde = 2.0 * A * e / (q1 * q1);
-                pi[np] = w + 2; pv[np] = adj_ln * log(f / p[w + 0]); np++;
-                pi[np] = w + 3; pv[np] = adj_ln / p[w + 3]; np++;
-                pi[np] = w + 5; pv[np] = -adj_ln / (p[w + 5] * q1); np++;
-                pi[np] = w + 1; pv[np] = adj_ln * dLde * (-2.0 / (p[w + 1] * D)); np++;
-                pi[np] = w + 4; pv[np] = adj_ln * dLde * (-2.0 * N / (D * D * p[w + 4])); np++;
-                pi[np] = w + 0; pv[np] = adj_ln * (-p[w + 2] / p[w + 0] + dLde * 2.0 * N / (D * D * p[w + 0])); np++;
-                adj_f += adj_ln * (p[w + 2] / f + dLde * 2.0 / (f * D));
-            }
-        }
-        pi[np] = M.idx_f; pv[np] = adj_f; np++;
-    }
+    // phase 1b: chain rule, one thread per multiplet (tm_bw_mult above)
+    for (int j = tid; j < nm; j += TM_BW_THREADS)
+        tm_bw_mult(L, &C, auxp + j, s_G + (size_t)j * TM_GSLOTS, p, shared_adj + (size_t)j * TM_NSHARED, pair_idx + j * TM_NPAIR,
+                   pair_val + j * TM_NPAIR);
     __syncthreads();
     BW_TS(3, 0);
 #if defined(TM_BW_STOP) && TM_BW_STOP == 3
@@ -662,7 +663,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int
     const int npairs_max = nm * TM_NPAIR + ncp;
     if (units < 1 || cells < 1 || tiles < 1) return (int)hipErrorInvalidValue;
     size_t lds = ((size_t)L.Nparams + (size_t)Nvars) * sizeof(double) + (size_t)npairs_max * sizeof(double) +
-                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + TM_MAXM) * sizeof(double) + 16 + (size_t)((npairs_max + 7) & ~7) * sizeof(int) +
+                 (size_t)nm * (TM_NSHARED + TM_GSLOTS) * sizeof(double) + 16 + (size_t)((npairs_max + 7) & ~7) * sizeof(int) +
                  (size_t)((tiles + 2) & ~1) * sizeof(int) + (size_t)((L.Nparams + 1) & ~1) * sizeof(int) +
                  (size_t)(TM_BW_THREADS / 64) * Nvars * sizeof(double);
     const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);
