@@ -646,6 +646,10 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     // over PCIe, where a scattered store is a transaction of its own (each thread stores what it has just summed)
     BW_TS(9, 0);
     for (int k = tid; k < Nvars; k += TM_BW_THREADS) grad[(size_t)chain * Nvars + k] = s_row[k];
+#ifdef TM_SU_TRACE   // the setup kernel's stamps (tamcmc_setup_body.h), handed on
+    __syncthreads();
+    if (tid < 20 && tid < Nvars) grad[(size_t)chain * Nvars + tid] = hser[(size_t)chain * cells * TM_MAXH * TM_HSER + tid];
+#endif
 #ifdef TM_BW_TRACE
     __syncthreads();
     if (tid < 20 && tid < Nvars) grad[(size_t)chain * Nvars + tid] = (double)(long long)(s_ts[tid] - s_ts[0]);

@@ -12,6 +12,11 @@
 
 // One workgroup of NT >= 192 threads per chain.  p: this chain's params row in LDS (L.Nparams doubles, filled here).
 // wave 0: multiplets; wave 1: noise record + tile polynomials; wave 2: m-ratios -- side by side.
+#ifdef TM_SU_TRACE   // timing-only build: cycle stamps of the phases leave through the chain's series table (tools/su_trace.py)
+#define SU_TS(i, who) do { if (tid == (who)) s_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SU_TS(i, who) do { } while (0)
+#endif
 template <int NT>
 __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain, const double *__restrict__ params,
                                               const double *__restrict__ Tcoefs, double *__restrict__ wt,
@@ -25,12 +30,19 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
     __shared__ int s_win[TM_MAXMULT][3];   // truncation windows and component counts, for the per-tile active lists
     __shared__ __attribute__((aligned(16))) int s_cost[TM_ORDER_MAX + 4];
     const int tid = threadIdx.x;
+#ifdef TM_SU_TRACE
+    __shared__ unsigned long long s_ts[20];
+    if (tid < 20) s_ts[tid] = 0;
+    __syncthreads();
+#endif
+    SU_TS(0, 0);
     for (int e = tid; e < L.Nparams; e += NT) p[e] = params[(size_t)chain * L.Nparams + e];
     // the caller's temperature array may live in host memory: read it once, now (latency hidden behind the work below)
     const double Tc = (tid == 64) ? Tcoefs[chain] : 1.0;
     __shared__ TmChain C;
     __shared__ int s_status;
     __syncthreads();
+    SU_TS(1, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 1
     return;   // timing-only build
 #endif
@@ -43,6 +55,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
 #endif
     }
     __syncthreads();
+    SU_TS(2, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 3
     return;   // timing-only build
 #endif
@@ -157,7 +170,11 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
 #endif
     const bool first = tid < 64 && tid < n_mult;
     if (first) tm_derive_mult_pre(L, C, p, tid, M);
+    SU_TS(3, 0);
+    SU_TS(4, 64);
+    SU_TS(5, 128);
     __syncthreads();     // ratios (wave 2) and the chain record are complete
+    SU_TS(6, 0);
     if (L.family != TM_FAM_GAUSS && chain_rec != nullptr)   // keep the chain record for the backward kernel (gradient path)
         for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += NT)
             reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
@@ -187,7 +204,9 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
             if (aux != nullptr) aux[(size_t)chain * L.n_mult + j] = M;
         }
     }
+    SU_TS(7, 0);
     __syncthreads();
+    SU_TS(8, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
     return;   // timing-only build
 #endif
@@ -294,6 +313,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
             }
         }
     }
+    SU_TS(9, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 4
     return;   // timing-only build
 #endif
@@ -320,8 +340,14 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         }
     }
     // a tile that had to be clamped (never expected) is reported through the chain status
+    SU_TS(10, 0);
     __syncthreads();
     if (tid == 64 && s_status != s_N.status) noise[chain].status = s_status;
+#ifdef TM_SU_TRACE
+    SU_TS(11, 0);
+    __syncthreads();
+    if (tid < 20 && hser != nullptr) hser[(size_t)chain * cells * TM_MAXH * TM_HSER + tid] = (double)(long long)(s_ts[tid] - s_ts[0]);
+#endif
 }
 #pragma clang fp contract(fast)
 
