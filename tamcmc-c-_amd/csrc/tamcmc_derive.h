@@ -177,17 +177,14 @@ __device__ inline int tm_window(const TmLayout &L, double fc_l, double f_s, doub
     return 0;
 }
 
-// Chain-level scalars (everything but the inclination -> m-ratio tables).  p = this chain's params row.
+// Chain-level scalars the multiplets need: everything but the inclination and the m-ratio tables (those are derived on
+// another wave meanwhile, tm_derive_chain_tables).  p = this chain's params row.
 __device__ inline void tm_derive_chain_scalars(const TmLayout &L, const double *p, TmChain &C)
 {
-    const double PI_L = 3.141592653589793238462643383279502884; // the reference's pi is long double; fp64 on the device
     const int id = L.model_case;
-    const int s = L.s, z = L.z, q = L.q;
-    C.a1 = 0.0; C.inc = 0.0; C.numax = 0.0; C.Htot = 0.0;
+    const int s = L.s, q = L.q;
+    C.a1 = 0.0; C.numax = 0.0; C.Htot = 0.0;
     C.Vl[0] = 1.0; C.Vl[1] = 0.0; C.Vl[2] = 0.0; C.Vl[3] = 0.0;
-    for (int l = 0; l < 4; l++)
-        for (int k = 0; k < TM_MAXM; k++) { C.ratios[l][k] = 0.0; C.dratios[l][k] = 0.0; }
-    C.ratios[0][0] = 1.0;
     C.trunc_c = p[q + L.Ninc];
     C.do_amp = (p[q + L.Ninc + 1] != 0.0) ? 1 : 0;
     C.eta = p[s + 1];
@@ -195,26 +192,11 @@ __device__ inline void tm_derive_chain_scalars(const TmLayout &L, const double *
     C.asym = p[s + 5];
     C.use_ratios = (L.variant != 2) ? 1 : 0;
 
-    if (id == 2 || id == 9 || id == 10 || id == 11) {
-        C.a1 = p[s + 3] * p[s + 3] + p[s + 4] * p[s + 4];
-        double inc = atan(p[s + 4] / p[s + 3]);
-        C.inc = (inc * 180.) / PI_L;
-    } else if (id == 3 || id == 6 || id == 7 || id == 8) {
-        C.inc = p[q];
-    }
+    if (id == 2 || id == 9 || id == 10 || id == 11) C.a1 = p[s + 3] * p[s + 3] + p[s + 4] * p[s + 4];
     if (id == 3 || id == 12 || id == 13 || id == 14) C.a1 = fabs(p[s]);
 
     if (L.family == TM_FAM_GLOBAL && id != 13) {
         for (int l = 1; l <= L.lmax; l++) C.Vl[l] = fabs(p[L.Nmax + l - 1]);
-    }
-    if (id == 12) {
-        // models.cpp:1010-1030 -- heights per |m| read from the inclination block
-        C.ratios[1][0] = fabs(p[q + 1]); C.ratios[1][1] = fabs(p[q + 0]); C.ratios[1][2] = fabs(p[q + 1]);
-        C.ratios[2][0] = fabs(p[q + 4]); C.ratios[2][1] = fabs(p[q + 3]); C.ratios[2][2] = fabs(p[q + 2]);
-        C.ratios[2][3] = fabs(p[q + 3]); C.ratios[2][4] = fabs(p[q + 4]);
-        C.ratios[3][0] = fabs(p[q + 8]); C.ratios[3][1] = fabs(p[q + 7]); C.ratios[3][2] = fabs(p[q + 6]);
-        C.ratios[3][3] = fabs(p[q + 5]); C.ratios[3][4] = fabs(p[q + 6]); C.ratios[3][5] = fabs(p[q + 7]);
-        C.ratios[3][6] = fabs(p[q + 8]);
     }
     if (id == 9) {
         // models.cpp:1372-1390
@@ -232,30 +214,53 @@ __device__ inline void tm_derive_chain_scalars(const TmLayout &L, const double *
     }
 }
 
-// m-height ratios from the inclination: nine (l, |m|) entries, one per lane (lanes 0..8), in parallel.
-__device__ inline void tm_derive_chain_ratios(const TmLayout &L, TmChain &C, int lane)
+// The stellar inclination in degrees (0 where the model has none)
+__device__ inline double tm_chain_inc(const TmLayout &L, const double *p)
 {
+    const double PI_L = 3.141592653589793238462643383279502884; // the reference's pi is long double; fp64 on the device
+    const int id = L.model_case;
+    if (id == 2 || id == 9 || id == 10 || id == 11) {
+        const double inc = atan(p[L.s + 4] / p[L.s + 3]);
+        return (inc * 180.) / PI_L;
+    }
+    if (id == 3 || id == 6 || id == 7 || id == 8) return p[L.q];
+    return 0.0;
+}
+
+// Inclination and m-height ratio tables, by ONE WAVE (all 64 lanes call this; contains wave-level synchronization only):
+// tables cleared, then either read from the inclination block (id 12, models.cpp:1010-1030) or derived from the
+// inclination, nine (l, |m|) entries on lanes 0..8 in parallel.
+__device__ inline void tm_derive_chain_tables(const TmLayout &L, const double *p, TmChain &C, int lane)
+{
+    const double inc = tm_chain_inc(L, p);            // every lane the same value: no exchange needed
+    if (lane < 4 * TM_MAXM) { (&C.ratios[0][0])[lane] = 0.0; (&C.dratios[0][0])[lane] = 0.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        const int q = L.q;
+        C.inc = inc;
+        C.ratios[0][0] = 1.0;
+        if (L.model_case == 12) {
+            C.ratios[1][0] = fabs(p[q + 1]); C.ratios[1][1] = fabs(p[q + 0]); C.ratios[1][2] = fabs(p[q + 1]);
+            C.ratios[2][0] = fabs(p[q + 4]); C.ratios[2][1] = fabs(p[q + 3]); C.ratios[2][2] = fabs(p[q + 2]);
+            C.ratios[2][3] = fabs(p[q + 3]); C.ratios[2][4] = fabs(p[q + 4]);
+            C.ratios[3][0] = fabs(p[q + 8]); C.ratios[3][1] = fabs(p[q + 7]); C.ratios[3][2] = fabs(p[q + 6]);
+            C.ratios[3][3] = fabs(p[q + 5]); C.ratios[3][4] = fabs(p[q + 6]); C.ratios[3][5] = fabs(p[q + 7]);
+            C.ratios[3][6] = fabs(p[q + 8]);
+        }
+    }
     if (L.model_case == 12 || L.variant == 2 || lane >= 9) return;
     const int l = (lane < 2) ? 1 : (lane < 5) ? 2 : 3;
     const int am = (lane < 2) ? lane : (lane < 5) ? lane - 2 : lane - 5;
     const bool need = (L.family == TM_FAM_GLOBAL) ? (L.lmax >= l) : (L.Nfl[l] >= 1);
     if (!need) return;
     const double PI = 3.141592653589793238462643;
-    const double angle = PI * C.inc / 180.;
+    const double angle = PI * inc / 180.;
     double dv;
     const double v = tm_dmm(l, am, 0, angle, &dv);
     const double r = v * v, dr = 2.0 * v * dv * (PI / 180.);
     C.ratios[l][l + am] = r; C.ratios[l][l - am] = r;
     C.dratios[l][l + am] = dr; C.dratios[l][l - am] = dr;
-}
-
-// Cooperative derivation by a whole workgroup (C in LDS).  Contains barriers: call from uniform code.
-__device__ inline void tm_derive_chain_coop(const TmLayout &L, const double *p, TmChain &C, int tid)
-{
-    if (tid == 0) tm_derive_chain_scalars(L, p, C);
-    __syncthreads();
-    tm_derive_chain_ratios(L, C, tid);
-    __syncthreads();
 }
 
 // (n, l) of multiplet j and the offset of degree l's block in local layouts

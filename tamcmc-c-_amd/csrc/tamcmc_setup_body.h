@@ -48,22 +48,25 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
 #endif
 
     if (tid == 0) s_status = 0;
-    // phase 1: the chain's scalars (one lane); everything below needs them
+    // The chain's scalars: lane 0 of wave 0, which goes on to the multiplets -- the only consumers -- without a workgroup
+    // barrier (LDS operations of one wave complete in order).  Inclination and m-ratio tables: wave 2, from the params
+    // row directly.  Wave 1: the noise record and the cell polynomials.  All three side by side.
     if (L.family != TM_FAM_GAUSS && tid == 0) {
 #if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))   // timing-only build: no chain-level derivation
         tm_derive_chain_scalars(L, p, C);
 #endif
     }
-    __syncthreads();
+    if (tid < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
     SU_TS(2, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 3
     return;   // timing-only build
 #endif
-    // phase 2, three waves side by side: wave 2 the m-ratios from the inclination, wave 1 the noise record and the
-    // tile polynomials, wave 0 every multiplet's record up to the products with those ratios
-    if (L.family != TM_FAM_GAUSS && tid >= 128) {
+    if (L.family != TM_FAM_GAUSS && tid >= 128 && tid < 192) {
 #if !(defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 4))
-        tm_derive_chain_ratios(L, C, tid - 128);
+        tm_derive_chain_tables(L, p, C, tid - 128);
 #endif
     }
 
