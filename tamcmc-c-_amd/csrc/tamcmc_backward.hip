@@ -296,6 +296,58 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         }
     }
     BW_TS(12, 0);
+    BW_TS(14, 192);
+    BW_TS(15, 0);
+    __syncthreads();
+    if (rv >= 0 && rv < L.Nparams) s_inv[rv] = rk;             // inverse of index_to_relax (the clears are behind the barrier)
+    for (int k = TM_BW_THREADS - 128 + tid; k < Nvars; k += TM_BW_THREADS) {   // more variables than staging threads
+        const int r = relax[k];
+        if (r >= 0 && r < L.Nparams) s_inv[r] = k;
+    }
+    BW_TS(1, 0);
+#if defined(TM_BW_STOP) && TM_BW_STOP == 1
+    return;   // timing-only build
+#endif
+
+    // ---------------- phase 1: per multiplet ----------------
+    // phase 1a: every (multiplet, slot) pair sums its tile partials in tile order -- all threads, LDS result
+    for (int item = tid; item < nm * TM_GSLOTS; item += TM_BW_THREADS) {
+        const int j = item / TM_GSLOTS, sl = item - j * TM_GSLOTS;
+        const TmMultFull &M = auxp[j];
+        double acc = 0.0;
+        if (M.status == 0 && (sl < M.ncomp || (sl >= 7 && sl < 12) || sl >= 21)) {      // B_k, A_am, C, asymmetry sums (tamcmc_eval_body.h)
+            // tiles whose units meet the window's units [ua, ub] (the multiplet is on their active lists).  Tiles of equal
+            // length (the default) are found by division; per-chain boundaries (equal-cost tiles) by a search over the
+            // tile starts: the first one is the tile holding unit ua -- the last tile that starts at or before it (empty
+            // tiles share a start with their successor and are passed over by taking the last).
+            const int ua = M.imin >> TM_UNIT_SHIFT, ub = (M.imax - 1) >> TM_UNIT_SHIFT;
+            if (uniform_su > 0) {
+                const int su = uniform_su, tA = ua / su, tB = (ub / su < tiles - 1) ? ub / su : tiles - 1;
+                const double *G = gmult + (((size_t)chain * tiles + tA) * nm + j) * TM_GSLOTS + sl;
+                const size_t stride = (size_t)nm * TM_GSLOTS;
+#pragma unroll 4
+                for (int t = tA; t <= tB; t++) acc += G[(size_t)(t - tA) * stride];
+            } else {
+                int lo = 0, hi = tiles - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_u[mid] <= ua) lo = mid; else hi = mid - 1;
+                }
+                for (int t = lo; t < tiles && s_u[t] <= ub; t++)
+                    if (s_u[t + 1] > s_u[t] && s_u[t + 1] > ua)
+                        acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
+            }
+        }
+        s_G[item] = acc;
+    }
+    __syncthreads();
+    BW_TS(2, 0);
+#if defined(TM_BW_STOP) && TM_BW_STOP == 2
+    return;   // timing-only build
+#endif
+    // Beside phase 1b (one wave, 21 lanes of it here, busy for ~2 us): the noise partials on wave 1 and the likelihood on
+    // wave 3 -- each one trip to memory and some arithmetic, consumed only after the next barrier.  (Ahead of the staging
+    // barrier they held the whole workgroup back by 0.7 us.)
     // noise partials: wave 1, one lane per (tile, cell part) (stride 64).  A tile meets at most two cells and leaves one
     // set of partials per cell.  On a cell whose background was evaluated as a polynomial the eval kernel left the
     // moments m_j = sum w dl^j (slot 9: j = 0, slot j-1: j = 1..9); with profile h's series u_h = sum c_j dl^j (setup
@@ -407,55 +459,6 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             if (status) status[chain] = st;
         }
     }
-    BW_TS(14, 192);
-    BW_TS(15, 0);
-    __syncthreads();
-    if (rv >= 0 && rv < L.Nparams) s_inv[rv] = rk;             // inverse of index_to_relax (the clears are behind the barrier)
-    for (int k = TM_BW_THREADS - 128 + tid; k < Nvars; k += TM_BW_THREADS) {   // more variables than staging threads
-        const int r = relax[k];
-        if (r >= 0 && r < L.Nparams) s_inv[r] = k;
-    }
-    BW_TS(1, 0);
-#if defined(TM_BW_STOP) && TM_BW_STOP == 1
-    return;   // timing-only build
-#endif
-
-    // ---------------- phase 1: per multiplet ----------------
-    // phase 1a: every (multiplet, slot) pair sums its tile partials in tile order -- all threads, LDS result
-    for (int item = tid; item < nm * TM_GSLOTS; item += TM_BW_THREADS) {
-        const int j = item / TM_GSLOTS, sl = item - j * TM_GSLOTS;
-        const TmMultFull &M = auxp[j];
-        double acc = 0.0;
-        if (M.status == 0 && (sl < M.ncomp || (sl >= 7 && sl < 12) || sl >= 21)) {      // B_k, A_am, C, asymmetry sums (tamcmc_eval_body.h)
-            // tiles whose units meet the window's units [ua, ub] (the multiplet is on their active lists).  Tiles of equal
-            // length (the default) are found by division; per-chain boundaries (equal-cost tiles) by a search over the
-            // tile starts: the first one is the tile holding unit ua -- the last tile that starts at or before it (empty
-            // tiles share a start with their successor and are passed over by taking the last).
-            const int ua = M.imin >> TM_UNIT_SHIFT, ub = (M.imax - 1) >> TM_UNIT_SHIFT;
-            if (uniform_su > 0) {
-                const int su = uniform_su, tA = ua / su, tB = (ub / su < tiles - 1) ? ub / su : tiles - 1;
-                const double *G = gmult + (((size_t)chain * tiles + tA) * nm + j) * TM_GSLOTS + sl;
-                const size_t stride = (size_t)nm * TM_GSLOTS;
-#pragma unroll 4
-                for (int t = tA; t <= tB; t++) acc += G[(size_t)(t - tA) * stride];
-            } else {
-                int lo = 0, hi = tiles - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (s_u[mid] <= ua) lo = mid; else hi = mid - 1;
-                }
-                for (int t = lo; t < tiles && s_u[t] <= ub; t++)
-                    if (s_u[t + 1] > s_u[t] && s_u[t + 1] > ua)
-                        acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
-            }
-        }
-        s_G[item] = acc;
-    }
-    __syncthreads();
-    BW_TS(2, 0);
-#if defined(TM_BW_STOP) && TM_BW_STOP == 2
-    return;   // timing-only build
-#endif
     // phase 1b: chain rule, one thread per multiplet (tm_bw_mult above)
     for (int j = tid; j < nm; j += TM_BW_THREADS)
         tm_bw_mult(L, &C, auxp + j, s_G + (size_t)j * TM_GSLOTS, p, shared_adj + (size_t)j * TM_NSHARED, pair_idx + j * TM_NPAIR,
