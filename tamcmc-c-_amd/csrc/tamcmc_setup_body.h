@@ -163,112 +163,21 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         }
     }
 
-    // wave 0: lane j derives multiplet j up to the ratio products, waits for the ratios, finishes it; chains with more
-    // than 64 multiplets do the rest afterwards in one go
-    TmMultFull M;        // in registers: every array index inside is a compile-time constant
-#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 2)   // timing-only build: no multiplet derivation
-    const int n_mult = 0;
-#else
-    const int n_mult = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
-#endif
-    const bool first = tid < 64 && tid < n_mult;
-    if (first) tm_derive_mult_pre(L, C, p, tid, M);
-    SU_TS(3, 0);
-    SU_TS(4, 64);
-    SU_TS(5, 128);
-    __syncthreads();     // ratios (wave 2) and the chain record are complete
-    SU_TS(6, 0);
-    if (L.family != TM_FAM_GAUSS && chain_rec != nullptr)   // keep the chain record for the backward kernel (gradient path)
-        for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += NT)
-            reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
-    if (tid < 64) {
-        for (int j = tid; j < n_mult; j += 64) {
-            if (j == tid) { if (first) tm_mult_apply_ratios(L, C, M); }
-            else tm_derive_mult(L, C, p, j, M);
-            TmMult out;
-            const double g2 = M.W * M.W;
-            out.g2 = g2;
-            if (C.asym == 0) {
-                out.aA = 0.0; out.aB = 1.0; out.c2 = 0.0; out.has_asym = 0;
-            } else {
-                // A(x) = (1 + asym (x/f - 1))^2 + (0.5 Gamma asym / f)^2, build_lorentzian.cpp:96
-                const double cc = 0.5 * M.W * C.asym / M.f;
-                out.aA = C.asym / M.f; out.aB = 1.0 - C.asym; out.c2 = cc * cc; out.has_asym = 1;
-            }
-#pragma unroll
-            for (int k = 0; k < TM_MAXM; k++) {
-                if (k < M.ncomp) { out.nu2[k] = 2.0 * M.nu[k]; out.hq[k] = M.h[k] * g2; }
-                else             { out.nu2[k] = 0.0;           out.hq[k] = 0.0; }
-            }
-            out.imin = M.imin; out.imax = M.imax; out.ncomp = M.ncomp;
-            s_win[j][0] = M.imin; s_win[j][1] = M.imax; s_win[j][2] = M.ncomp;
-            if (M.status != 0) atomicMax(&s_status, M.status);
-            mult[(size_t)chain * L.n_mult + j] = out;
-            if (aux != nullptr) aux[(size_t)chain * L.n_mult + j] = M;
-        }
-    }
-    SU_TS(7, 0);
-    __syncthreads();
-    SU_TS(8, 0);
-#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
-    return;   // timing-only build
-#endif
-    if (tid == 64) {
-        s_N.status = s_status;
-        wt[2 * chain] = Tc;                  // device copy for the eval / backward kernels
-        wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
-        noise[chain] = s_N;
-    }
-
     // ---------------- tiles: per-chain boundaries, active multiplet lists, launch ranks ----------------
     __shared__ int s_b[TM_ORDER_MAX + 2];      // tile boundaries in units (tiles <= TM_ORDER_MAX; else computed on the fly)
     __shared__ int s_tot[2];                   // total cost, cheapest unit
     const int nm = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
     const bool eq = tm_setup_balances(units, tiles, equal_cost, cm.pad) != 0 && s_pre != nullptr;
     const int su = (units + tiles - 1) / tiles;       // uniform tiles: su units each (su <= TM_TILE_MAXU by the tile count)
-    if (eq) {
-        // Equal-cost tiles.  (1) cost of every unit from the windows; (2) inclusive prefix sum (one wave: each lane a
-        // contiguous chunk, then a wave scan); (3) every boundary by a binary search in the prefix (tm_tile_bound,
-        // tamcmc_dev.h: integer arithmetic, tiles of at most TM_TILE_MAXU units guaranteed).
-        for (int u = tid; u < units; u += NT) {
-            const int lo = u << TM_UNIT_SHIFT, hi = lo + TM_UNIT_BINS;
-            int c = cm.c0;
-            for (int j = 0; j < nm; j++)
-                if (s_win[j][0] < hi && s_win[j][1] > lo) c += cm.a * s_win[j][2] + cm.b;
-            s_pre[u] = c;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int ch = (units + 63) >> 6;
-            const int lo = tid * ch, hi = (lo + ch < units) ? lo + ch : units;
-            int sum = 0, mn = 0x7fffffff;
-            for (int u = lo; u < hi; u++) { const int c = s_pre[u]; sum += c; mn = c < mn ? c : mn; }
-            int incl = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (tid >= off) incl += t; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mn, off, 64); mn = t < mn ? t : mn; }
-            int run = incl - sum;
-            for (int u = lo; u < hi; u++) { run += s_pre[u]; s_pre[u] = run; }
-            if (tid == 63) { s_tot[0] = incl; s_tot[1] = mn; }
-        }
-        __syncthreads();
-        const long long C = s_tot[0], cmin = s_tot[1];
-        for (int t = tid; t <= tiles; t += NT) {
-            const int b = (t == 0) ? 0 : (t == tiles) ? units : tm_tile_bound(t, tiles, units, s_pre, C, cmin);
-            s_b[t] = b;
-        }
-        __syncthreads();
-    }
     // The multiplets whose window meets the tile, in table order (this fixes the summation order of the eval kernel).
     // One GROUP of lanes per tile, one lane per multiplet: the windows come out of LDS side by side, a ballot compacts the
     // active ones in table order, and the tile's cost comes from ballots per component count -- scalar popcounts, no
     // exchange between lanes (a lane walking a tile's multiplets one after the other took 3 us of dependent LDS round
-    // trips; with three waves instead of eight the pass took 2 us longer).  A group is a whole wave, or a half / quarter
+    // trips; with three waves instead of eight the pass took 2 us longer).  The waves w_first .. w_first + NW - 1 share the
+    // tiles (all their lanes must make the call).  A group is a whole wave, or a half / quarter
     // of one when the chain has at most 32 / 16 multiplets: every wave then lists two / four tiles at a time.
-    {
-        const int lane = tid & 63, wv = tid >> 6;
-        constexpr int NW = NT / 64;
+    auto tile_pass = [&](const int w_first, const int NW) __attribute__((always_inline)) {
+        const int lane = tid & 63, wv = (tid >> 6) - w_first;
         const int gshift = (nm <= 16) ? 4 : (nm <= 32) ? 5 : 6;            // log2(lanes per group)
         const int G = 1 << gshift, gpw = 64 >> gshift;                     // lanes per group, groups per wave
         const int g = lane >> gshift, gl = lane & (G - 1);
@@ -315,7 +224,109 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
                 if (tile < TM_ORDER_MAX) s_cost[tile] = ((cost < (1 << 20) ? cost : (1 << 20)) << 10) + (TM_ORDER_MAX - 1 - tile);
             }
         }
+    };
+
+    // wave 0: lane j derives multiplet j up to the ratio products, waits for the ratios, finishes it; chains with more
+    // than 64 multiplets do the rest afterwards in one go
+    TmMultFull M;        // in registers: every array index inside is a compile-time constant
+#if defined(TM_SETUP_SKIP) && (TM_SETUP_SKIP & 2)   // timing-only build: no multiplet derivation
+    const int n_mult = 0;
+#else
+    const int n_mult = (L.family != TM_FAM_GAUSS) ? L.n_mult : 0;
+#endif
+    const bool first = tid < 64 && tid < n_mult;
+    // The windows do not depend on the m-ratios: when one wave holds every multiplet and the tiles have equal length,
+    // they are published before the barrier below, and the other waves list the tiles while wave 0 completes and stores
+    // the records (3 400 of the kernel's 23 000 cycles side by side instead of one after the other).
+    const bool early_tiles = (n_mult <= 64) && !eq && (NT >= 128);
+    if (first) {
+        tm_derive_mult_pre(L, C, p, tid, M);
+        if (early_tiles) { s_win[tid][0] = M.imin; s_win[tid][1] = M.imax; s_win[tid][2] = M.ncomp; }
     }
+    SU_TS(3, 0);
+    SU_TS(4, 64);
+    SU_TS(5, 128);
+    __syncthreads();     // ratios (wave 2) and the chain record are complete
+    SU_TS(6, 0);
+    if (L.family != TM_FAM_GAUSS && chain_rec != nullptr)   // keep the chain record for the backward kernel (gradient path)
+        for (int e = tid; e < (int)(sizeof(TmChain) / sizeof(double)); e += NT)
+            reinterpret_cast<double *>(chain_rec + chain)[e] = reinterpret_cast<const double *>(&C)[e];
+    if (tid < 64) {
+        for (int j = tid; j < n_mult; j += 64) {
+            if (j == tid) { if (first) tm_mult_apply_ratios(L, C, M); }
+            else tm_derive_mult(L, C, p, j, M);
+            TmMult out;
+            const double g2 = M.W * M.W;
+            out.g2 = g2;
+            if (C.asym == 0) {
+                out.aA = 0.0; out.aB = 1.0; out.c2 = 0.0; out.has_asym = 0;
+            } else {
+                // A(x) = (1 + asym (x/f - 1))^2 + (0.5 Gamma asym / f)^2, build_lorentzian.cpp:96
+                const double cc = 0.5 * M.W * C.asym / M.f;
+                out.aA = C.asym / M.f; out.aB = 1.0 - C.asym; out.c2 = cc * cc; out.has_asym = 1;
+            }
+#pragma unroll
+            for (int k = 0; k < TM_MAXM; k++) {
+                if (k < M.ncomp) { out.nu2[k] = 2.0 * M.nu[k]; out.hq[k] = M.h[k] * g2; }
+                else             { out.nu2[k] = 0.0;           out.hq[k] = 0.0; }
+            }
+            out.imin = M.imin; out.imax = M.imax; out.ncomp = M.ncomp;
+            if (!early_tiles) { s_win[j][0] = M.imin; s_win[j][1] = M.imax; s_win[j][2] = M.ncomp; }
+            if (M.status != 0) atomicMax(&s_status, M.status);
+            mult[(size_t)chain * L.n_mult + j] = out;
+            if (aux != nullptr) aux[(size_t)chain * L.n_mult + j] = M;
+        }
+    }
+    SU_TS(7, 0);
+    if (early_tiles && tid >= 64) tile_pass(1, NT / 64 - 1);
+    __syncthreads();
+    SU_TS(8, 0);
+#if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
+    return;   // timing-only build
+#endif
+    if (tid == 64) {
+        s_N.status = s_status;
+        wt[2 * chain] = Tc;                  // device copy for the eval / backward kernels
+        wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
+        noise[chain] = s_N;
+    }
+
+    // ---------------- tiles: per-chain boundaries (balanced mode), active multiplet lists unless done, launch ranks ----------------
+    if (eq) {
+        // Equal-cost tiles.  (1) cost of every unit from the windows; (2) inclusive prefix sum (one wave: each lane a
+        // contiguous chunk, then a wave scan); (3) every boundary by a binary search in the prefix (tm_tile_bound,
+        // tamcmc_dev.h: integer arithmetic, tiles of at most TM_TILE_MAXU units guaranteed).
+        for (int u = tid; u < units; u += NT) {
+            const int lo = u << TM_UNIT_SHIFT, hi = lo + TM_UNIT_BINS;
+            int c = cm.c0;
+            for (int j = 0; j < nm; j++)
+                if (s_win[j][0] < hi && s_win[j][1] > lo) c += cm.a * s_win[j][2] + cm.b;
+            s_pre[u] = c;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int ch = (units + 63) >> 6;
+            const int lo = tid * ch, hi = (lo + ch < units) ? lo + ch : units;
+            int sum = 0, mn = 0x7fffffff;
+            for (int u = lo; u < hi; u++) { const int c = s_pre[u]; sum += c; mn = c < mn ? c : mn; }
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (tid >= off) incl += t; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mn, off, 64); mn = t < mn ? t : mn; }
+            int run = incl - sum;
+            for (int u = lo; u < hi; u++) { run += s_pre[u]; s_pre[u] = run; }
+            if (tid == 63) { s_tot[0] = incl; s_tot[1] = mn; }
+        }
+        __syncthreads();
+        const long long C = s_tot[0], cmin = s_tot[1];
+        for (int t = tid; t <= tiles; t += NT) {
+            const int b = (t == 0) ? 0 : (t == tiles) ? units : tm_tile_bound(t, tiles, units, s_pre, C, cmin);
+            s_b[t] = b;
+        }
+        __syncthreads();
+    }
+    if (!early_tiles) tile_pass(0, NT / 64);
     SU_TS(9, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 4
     return;   // timing-only build
