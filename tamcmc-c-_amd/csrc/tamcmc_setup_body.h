@@ -278,18 +278,18 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         }
     }
     SU_TS(7, 0);
+    if (tid == 64) {       // the noise record is complete (this wave built it): out it goes; its status follows at the very end
+        s_N.status = 0;
+        wt[2 * chain] = Tc;                  // device copy for the eval / backward kernels
+        wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
+        noise[chain] = s_N;
+    }
     if (early_tiles && tid >= 64) tile_pass(1, NT / 64 - 1);
     __syncthreads();
     SU_TS(8, 0);
 #if defined(TM_SETUP_STOP) && TM_SETUP_STOP == 2
     return;   // timing-only build
 #endif
-    if (tid == 64) {
-        s_N.status = s_status;
-        wt[2 * chain] = Tc;                  // device copy for the eval / backward kernels
-        wt[2 * chain + 1] = (L.likelihood_case == 0) ? L.like_p / Tc : 2.0 / Tc;
-        noise[chain] = s_N;
-    }
 
     // ---------------- tiles: per-chain boundaries (balanced mode), active multiplet lists unless done, launch ranks ----------------
     if (eq) {
@@ -356,7 +356,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
     // a tile that had to be clamped (never expected) is reported through the chain status
     SU_TS(10, 0);
     __syncthreads();
-    if (tid == 64 && s_status != s_N.status) noise[chain].status = s_status;
+    if (tid == 64 && s_status != 0) noise[chain].status = s_status;
 #ifdef TM_SU_TRACE
     SU_TS(11, 0);
     __syncthreads();
