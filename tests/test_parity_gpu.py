@@ -307,6 +307,15 @@ def test_launch_order_does_not_change_results(accel_mod, orc, monkeypatch):
     check_logL(L, rL)
     check_logL(Lg, rL)
     assert np.all(np.isfinite(g))
+    # the same gradient from the default geometry (293 tiles, ranked launch order)
+    monkeypatch.delenv("TAMCMC_TILES")
+    monkeypatch.delenv("TAMCMC_TILES_GRAD")
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        assert acc.geometry()["tiles"] < 1024
+        Ld, std, gd = acc.eval_batch(P, T, grad=True)
+    check_logL(Ld, rL)
+    assert np.max(np.abs(g - gd) / np.max(np.abs(gd), axis=1, keepdims=True)) < 1e-10
 
 
 def test_equal_cost_tiles_follow_the_chain_not_the_batch(accel_mod, orc, monkeypatch):
