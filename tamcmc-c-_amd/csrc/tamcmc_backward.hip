@@ -4,14 +4,20 @@
 // CPU oracle's log-likelihood only ("parity unpinned").  The truncation window [imin,imax) moves
 // with the parameters; like any analytic gradient of a truncated model this ignores the motion.
 //
-// One workgroup (256 threads) per chain.  The chain record (TmChain) and the per-multiplet records
-// (TmMultFull) written by the setup kernel are read back instead of being re-derived.
-// Phase 0: wave 3 sums the likelihood partials (the finalize step: logL, status); lanes 64..79 sum the
-// noise partials.  Phase 1: thread j sums multiplet j's partials over the tiles its window touches IN
-// TILE ORDER and emits (param index, value) pairs plus chain-level adjoints into LDS.  Phase 2: the
-// chain-level adjoints are summed over multiplets (one thread per slot, multiplet order) and thread 0
-// turns them (splitting, inclination, visibilities, asymmetry, numax, noise) into more pairs.
-// Phase 3: thread k gathers, in pair order, everything addressed to variable k.
+// One workgroup (512 threads) per chain.  The chain record (TmChain) and the per-multiplet records
+// (TmMultFull) written by the setup kernel are read back instead of being re-derived.  The kernel is a chain of
+// single-wave stages separated by trips to memory (~1 us each: its inputs were written by other XCDs), so its
+// shape follows the time line measured with cycle stamps inside it (TM_BW_TRACE, tools/bw_trace.py):
+// Staging: six waves issue every load of the LDS copies (params row, records, tile starts, chain record, inverse
+//   of index_to_relax) at once, clear the pair tables while those are in flight, then store.
+// Phase 1a: every (multiplet, slot) pair sums its partials over the tiles the window touches IN TILE ORDER.
+// Phase 1b: lane j runs multiplet j's chain rule (tm_bw_mult) and emits (param index, value) pairs plus
+//   chain-level adjoints into LDS; beside it wave 1 sums the noise partials and wave 3 the likelihood partials
+//   (the finalize step: logL, status) -- each one trip to memory of its own.
+// Phase 2: the chain-level adjoints are summed over multiplets (four lanes per slot, multiplet order) and two
+//   lanes on two waves turn them (splitting, inclination, visibilities, asymmetry, numax | noise) into more pairs.
+// Phase 3: every variable gathers, in pair order, what is addressed to it: per 64-pair chunk one ballot per
+//   variable tells lane k which pairs are its own; the waves' partial rows are added in wave order.
 // No atomics: bitwise reproducible.  Compiled with -ffp-contract=off like the setup TU.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
@@ -296,7 +302,6 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         }
     }
     BW_TS(12, 0);
-    BW_TS(14, 192);
     BW_TS(15, 0);
     __syncthreads();
     if (rv >= 0 && rv < L.Nparams) s_inv[rv] = rk;             // inverse of index_to_relax (the clears are behind the barrier)
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             if (status) status[chain] = st;
         }
     }
+    BW_TS(14, 192);
     // phase 1b: chain rule, one thread per multiplet (tm_bw_mult above)
     for (int j = tid; j < nm; j += TM_BW_THREADS)
         tm_bw_mult(L, &C, auxp + j, s_G + (size_t)j * TM_GSLOTS, p, shared_adj + (size_t)j * TM_NSHARED, pair_idx + j * TM_NPAIR,

@@ -2,16 +2,19 @@
 // equal-cost tile boundaries, active-multiplet lists and launch ranks.  Compiled with -ffp-contract=off (see tamcmc_derive.h); the body lives in
 // tamcmc_setup_body.h, which the fused small-grid kernel (tamcmc_fused.hip) shares.
 //
-// One workgroup of three waves per chain: one lane derives the chain's scalars, then wave 0 derives the multiplets,
-// wave 1 the noise record and the per-tile background polynomials, wave 2 the m-ratios, side by side.  The work is
-// O(Nparams) per chain (microseconds); it exists as a kernel so that a sampler can keep params resident in HBM and
-// chain the whole evaluation on one stream without a host round trip.
+// One workgroup of eight waves per chain.  Three work side by side on the params row: wave 0 (lane 0 the chain's
+// scalars, then a lane per multiplet) the multiplet records, wave 1 the noise record and the per-cell background
+// polynomials, wave 2 the inclination and the m-ratio tables.  The truncation windows do not depend on the ratios, so
+// they are published first and waves 1..7 build the tiles' active lists while wave 0 completes and stores the records;
+// launch ranks last.  The work is O(Nparams) per chain -- a chain of single-wave stages (time line: TM_SU_TRACE,
+// tools/su_trace.py); it exists as a kernel so that a sampler can keep params resident in HBM and chain the whole
+// evaluation on one stream without a host round trip.
 #include <hip/hip_runtime.h>
 #include "tamcmc_dev.h"
 #include "tamcmc_setup_body.h"
 
 #ifndef TM_SETUP_THREADS
-#define TM_SETUP_THREADS 512   // wave 0: multiplets; wave 1: noise record + cell polynomials; wave 2: m-ratios -- concurrently; all eight: tile lists
+#define TM_SETUP_THREADS 512
 #endif
 __global__ __launch_bounds__(TM_SETUP_THREADS) void tamcmc_setup_kernel(TmLayout L, const double *__restrict__ params,
                                                           const double *__restrict__ Tcoefs, double *__restrict__ wt,

@@ -10,7 +10,7 @@
 #pragma clang fp contract(off)
 #include "tamcmc_derive.h"
 
-// One workgroup of NT >= 192 threads per chain.  p: this chain's params row in LDS (L.Nparams doubles, filled here).
+// One workgroup of NT >= 192 threads (whole waves) per chain.  p: this chain's params row in LDS (L.Nparams doubles, filled here).
 // wave 0: multiplets; wave 1: noise record + tile polynomials; wave 2: m-ratios -- side by side.
 #ifdef TM_SU_TRACE   // timing-only build: cycle stamps of the phases leave through the chain's series table (tools/su_trace.py)
 #define SU_TS(i, who) do { if (tid == (who)) s_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
