@@ -406,6 +406,12 @@ extern "C" int tamcmc_ctx_profile(tamcmc_ctx *c, int enable)
     c->profile_stride = enable > 1 ? enable : 1;
     c->profile_count = 0;
     c->ev_used = 0;
+    // a pool of events up front: creating one costs ~10 us, which would land inside the caller's timed region
+    while (c->profile && c->ev.size() < 256) {
+        hipEvent_t e;
+        TM_HIP(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
     return TAMCMC_OK;
 }
 
