@@ -52,6 +52,12 @@ struct TmMultFull {
 
 static_assert(sizeof(TmMultFull) % sizeof(double) == 0, "TmMultFull is copied as doubles");
 
+#ifdef TM_SU_TRACE_FINE
+__shared__ unsigned long long g_fine[8];
+#define FINE_TS(i) do { if (threadIdx.x == 0) g_fine[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FINE_TS(i) do { } while (0)
+#endif
 __device__ __forceinline__ double tm_ipow(double b, int e)
 {
     double r = 1.0;
@@ -120,7 +126,19 @@ __device__ inline double tm_lin_interpol(const double *x, const double *y, int N
     double a = 0, b = 0;
     int n0 = 0, n1 = 1;
     if (x_int >= x[0] && x_int <= x[Nx - 1]) {
-        while ((x_int < x[i] || x_int > x[i + 1]) && i < Nx - 2) i = i + 1; // bracket always exists; bound guards NaN rows
+        // The reference walks i = 0, 1, ... while (x_int < x[i] || x_int > x[i+1]) && i < Nx-2: the first bracket that
+        // holds x_int, or Nx-2.  Same result from nine nodes fetched at a time (a lane runs this alone: one LDS round
+        // trip per step of the walk was 40 % of the multiplet's derivation).
+        i = Nx - 2;
+        bool found = false;
+        for (int base = 0; base < Nx - 1 && !found; base += 8) {
+            double xv[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) xv[q] = x[(base + q < Nx - 1) ? base + q : Nx - 1];
+#pragma unroll
+            for (int q = 7; q >= 0; q--)
+                if (base + q <= Nx - 2 && !(x_int < xv[q] || x_int > xv[q + 1])) { i = base + q; found = true; }
+        }
         a = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
         b = y[i] - a * x[i];
         n0 = i; n1 = i + 1;
@@ -233,6 +251,9 @@ __device__ inline double tm_chain_inc(const TmLayout &L, const double *p)
 __device__ inline void tm_derive_chain_tables(const TmLayout &L, const double *p, TmChain &C, int lane)
 {
     const double inc = tm_chain_inc(L, p);            // every lane the same value: no exchange needed
+#ifdef TM_SU_TRACE_FINE
+    if (threadIdx.x == 128) g_fine[6] = __builtin_amdgcn_s_memtime();
+#endif
     if (lane < 4 * TM_MAXM) { (&C.ratios[0][0])[lane] = 0.0; (&C.dratios[0][0])[lane] = 0.0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -256,6 +277,9 @@ __device__ inline void tm_derive_chain_tables(const TmLayout &L, const double *p
     if (!need) return;
     const double PI = 3.141592653589793238462643;
     const double angle = PI * inc / 180.;
+#ifdef TM_SU_TRACE_FINE
+    if (threadIdx.x == 128) g_fine[7] = __builtin_amdgcn_s_memtime();
+#endif
     double dv;
     const double v = tm_dmm(l, am, 0, angle, &dv);
     const double r = v * v, dr = 2.0 * v * dv * (PI / 180.);
@@ -291,6 +315,7 @@ __device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, c
     M.slope = 0.0;
     M.status = 0;
 
+    FINE_TS(0);
     // ---- frequency ----
     M.idx_f = L.off_f[l] + n;
     M.f = p[M.idx_f];
@@ -308,6 +333,7 @@ __device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, c
         M.f_s_win = M.f_s1;
     }
 
+    FINE_TS(1);
     // ---- width ----
     if (L.family == TM_FAM_LOCAL) {
         M.width_kind = 0;
@@ -340,6 +366,7 @@ __device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, c
     }
     M.W = (M.width_kind == 2 || M.width_kind == 3) ? M.Wraw : fabs(M.Wraw);
 
+    FINE_TS(2);
     // ---- heights ----
     M.H = 0.0;
 #pragma unroll
@@ -374,6 +401,7 @@ __device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, c
         }
     }
 
+    FINE_TS(3);
     // ---- component frequencies ----  build_lorentzian.cpp:74-91 / :28-48
     // (fixed trip count + predicate: the record stays in registers, the seven components are independent chains)
 #pragma unroll
@@ -382,9 +410,15 @@ __device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, c
         double Qlm = 0.0, clm = 0.0, nu = 0.0;
         if (k < M.ncomp) {
             if (l != 0) {
-                Qlm = (double)(l * (l + 1) - 3 * m * m) / (double)((2 * l - 1) * (2 * l + 3));
+                // Q_lm = (l(l+1) - 3 m^2) / ((2l-1)(2l+3)) and, for l = 2, c_lm = (5 m^3 - 17 m) / 3: quotients of small
+                // integers, the same correctly rounded doubles whether divided at run time or folded by the compiler (k is a
+                // constant in each copy of this unrolled loop; only l is not)
+                const int k1 = k - 1, k2 = k - 2, k3 = k - 3;         // m for l = 1, 2, 3
+                const double q1 = (double)(2 - 3 * k1 * k1) / 5.0, q2 = (double)(6 - 3 * k2 * k2) / 21.0, q3 = (double)(12 - 3 * k3 * k3) / 45.0;
+                const double c2 = (5. * (double)(k2 * k2 * k2) - 17. * k2) / 3.;
+                Qlm = (l == 1) ? q1 : (l == 2) ? q2 : q3;
                 if (l == 1) clm = (L.variant == 1) ? 0.0 : (double)m;
-                if (l == 2) clm = (5. * (double)(m * m * m) - 17. * m) / 3.;
+                if (l == 2) clm = c2;
                 if (l == 3) clm = 0.0;
                 nu = M.f * (1. + C.eta * Qlm) + m * M.f_s + clm * C.a3;
             } else {
@@ -394,8 +428,10 @@ __device__ inline void tm_derive_mult_pre(const TmLayout &L, const TmChain &C, c
         M.nu[k] = nu; M.Q[k] = Qlm; M.c[k] = clm;
     }
 
+    FINE_TS(4);
     // ---- truncation window ----
     M.status = tm_window(L, M.f, M.f_s_win, M.W, l, C.trunc_c, &M.imin, &M.imax);
+    FINE_TS(5);
 }
 
 // h_m = H_l times the m-ratio (variants 0 and 1; variant 2 read its heights from params already)

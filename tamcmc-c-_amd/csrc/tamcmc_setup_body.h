@@ -361,6 +361,9 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
     SU_TS(11, 0);
     __syncthreads();
     if (tid < 20 && hser != nullptr) hser[(size_t)chain * cells * TM_MAXH * TM_HSER + tid] = (double)(long long)(s_ts[tid] - s_ts[0]);
+#ifdef TM_SU_TRACE_FINE
+    if (tid < 8 && hser != nullptr) hser[(size_t)chain * cells * TM_MAXH * TM_HSER + 12 + tid] = (double)(long long)(g_fine[tid] - s_ts[0]);
+#endif
 #endif
 }
 #pragma clang fp contract(fast)
