@@ -270,18 +270,41 @@ __device__ inline void tm_derive_chain_tables(const TmLayout &L, const double *p
             C.ratios[3][6] = fabs(p[q + 8]);
         }
     }
-    if (L.model_case == 12 || L.variant == 2 || lane >= 9) return;
-    const int l = (lane < 2) ? 1 : (lane < 5) ? 2 : 3;
-    const int am = (lane < 2) ? lane : (lane < 5) ? lane - 2 : lane - 5;
-    const bool need = (L.family == TM_FAM_GLOBAL) ? (L.lmax >= l) : (L.Nfl[l] >= 1);
-    if (!need) return;
+    if (L.model_case == 12 || L.variant == 2) return;      // (wave-uniform: every lane leaves or none)
+    // d^l_{|m|,0}(beta) of function_rot.cpp:81-93 is a sum of up to four terms: four lanes per (l, |m|) entry compute one
+    // term each -- the same expressions as tm_dmm -- and the entry's first lane adds them in the order of the
+    // reference's loop (a lane alone took 7 600 cycles for the sum, the longest stage of the setup kernel).
+    const int item = lane >> 2, s_ = lane & 3;             // items 0..8: (l, |m|) = (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) .. (3,3)
+    const int l = (item < 2) ? 1 : (item < 5) ? 2 : 3;
+    const int am = (item < 2) ? item : (item < 5) ? item - 2 : (item < 9) ? item - 5 : 0;
+    const bool need = (item < 9) && ((L.family == TM_FAM_GLOBAL) ? (L.lmax >= l) : (L.Nfl[l] >= 1));
     const double PI = 3.141592653589793238462643;
     const double angle = PI * inc / 180.;
 #ifdef TM_SU_TRACE_FINE
     if (threadIdx.x == 128) g_fine[7] = __builtin_amdgcn_s_memtime();
 #endif
-    double dv;
-    const double v = tm_dmm(l, am, 0, angle, &dv);
+    const double cb = cos(angle / 2.), sb = sin(angle / 2.);
+    const bool live = s_ <= l - am;                        // this lane's term exists
+    const int ec = 2 * s_ + am, es = 2 * l - 2 * s_ - am;
+    double coef = (double)tm_combi(l, l - am - s_) * (double)tm_combi(l, s_);   // function_rot.cpp:85 with m2 = 0
+    if ((l - am - s_) & 1) coef = -coef;
+    double term = coef * tm_ipow(cb, ec) * tm_ipow(sb, es);
+    // d/dbeta [c^ec s^es] = 0.5 * (es c^(ec+1) s^(es-1) - ec c^(ec-1) s^(es+1))
+    double d = 0.0;
+    if (es > 0) d += 0.5 * es * tm_ipow(cb, ec + 1) * tm_ipow(sb, es - 1);
+    if (ec > 0) d -= 0.5 * ec * tm_ipow(cb, ec - 1) * tm_ipow(sb, es + 1);
+    double dterm = coef * d;
+    if (!live) { term = 0.0; dterm = 0.0; }
+    const double t1 = __shfl_down(term, 1, 4), t2 = __shfl_down(term, 2, 4), t3 = __shfl_down(term, 3, 4);
+    const double d1 = __shfl_down(dterm, 1, 4), d2 = __shfl_down(dterm, 2, 4), d3 = __shfl_down(dterm, 3, 4);
+    if (!need || s_ != 0) return;
+    double sum = 0.0 + term, dsum = 0.0 + dterm;           // the loop's running sums, s = 0 .. l - |m|
+    if (l - am >= 1) { sum = sum + t1; dsum = dsum + d1; }
+    if (l - am >= 2) { sum = sum + t2; dsum = dsum + d2; }
+    if (l - am >= 3) { sum = sum + t3; dsum = dsum + d3; }
+    const double nrm = sqrt((double)(tm_factorial(l + am) * tm_factorial(l - am))) /
+                       sqrt((double)(tm_factorial(l) * tm_factorial(l)));
+    const double v = sum * nrm, dv = dsum * nrm;
     const double r = v * v, dr = 2.0 * v * dv * (PI / 180.);
     C.ratios[l][l + am] = r; C.ratios[l][l - am] = r;
     C.dratios[l][l + am] = dr; C.dratios[l][l - am] = dr;
