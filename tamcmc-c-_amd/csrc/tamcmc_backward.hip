@@ -28,7 +28,15 @@
 #else
 #define BW_TS(i, who) do { } while (0)
 #endif
+#ifdef TM_BW_TRACE
+__shared__ unsigned long long g_bfine[8];
+#define BFINE(i) do { if (threadIdx.x == 0) g_bfine[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BFINE(i) do { } while (0)
+#endif
 #define NWV_ROWS (TM_BW_THREADS / 64)
+#define TM_GSTRIDE (TM_GSLOTS + 1)   // row stride of the tile-summed partials in LDS: 25 doubles, so that the lanes of phase 1b
+                                     // (one multiplet each, reading the same slot of their rows) fall on different banks
 #define TM_NPAIR 12   // pairs a multiplet can emit
 #define TM_NSHARED 20 // chain-level adjoint slots per multiplet
 #define TM_NCPAIR 64  // base number of chain-level pairs (plus numax pairs for id 9)
@@ -59,6 +67,7 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
     const TmChain &C = *Cp;
     const TmMultFull &M = *Mp;
     int np = 0;
+    BFINE(0);
     if (M.status != 0) return;
     const int l = M.l;
     const double W = M.W, g2 = W * W, f = M.f;
@@ -68,33 +77,40 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
     // sum_k hq_k r_k^2.
     double s_eta = 0.0, s_a3 = 0.0;
     const int ncomp = M.ncomp;
+    // Every operand is fetched unconditionally (all indices are inside the records whatever l is) and the per-component
+    // tests become selects: behind a branch per component the compiler issues that component's LDS loads only once the
+    // branch is taken, one round trip after the other (2 100 cycles for this block; the sums are the same).
+    double Gk[TM_MAXM], hk[TM_MAXM], Qk[TM_MAXM], ck[TM_MAXM], GA[4], hA[4];
+#pragma unroll
+    for (int k = 0; k < TM_MAXM; k++) { Gk[k] = G[k]; hk[k] = M.h[k]; Qk[k] = M.Q[k]; ck[k] = M.c[k]; }
+#pragma unroll
+    for (int am = 0; am <= 3; am++) { GA[am] = G[7 + am]; hA[am] = M.h[(l + am < TM_MAXM) ? l + am : TM_MAXM - 1]; }
+    const double eta = C.eta;
     double adj_g2 = -G[11];
     double ah[4];                       // d/d(h) of the pair of components +-am (kept at the +m component), am = 0..l
 #pragma unroll
     for (int am = 0; am <= 3; am++) {
-        ah[am] = 0.0;
-        if (am <= l) {
-            const double A = G[7 + am];                 // d/d(hq) summed over the components l-am and l+am
-            adj_g2 += A * M.h[l + am];
-            ah[am] = A * g2;
-        }
+        const bool on = am <= l;
+        const double A = GA[am];                        // d/d(hq) summed over the components l-am and l+am
+        adj_g2 = on ? adj_g2 + A * hA[am] : adj_g2;
+        ah[am] = on ? A * g2 : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < TM_MAXM; k++) {
-        if (k < ncomp) {
-            const double hq = M.h[k] * g2;
-            const double adj_nu = 4.0 * hq * G[k];
-            const int m = k - l;
-            if (l != 0) {
-                adj_f += adj_nu * (1. + C.eta * M.Q[k]);
-                s_eta += adj_nu * f * M.Q[k];
-                adj_fs += adj_nu * (double)m;
-                s_a3 += adj_nu * M.c[k];
-            } else {
-                adj_f += adj_nu;
-            }
+        const bool on = k < ncomp;
+        const double hq = hk[k] * g2;
+        const double adj_nu = 4.0 * hq * Gk[k];
+        const int m = k - l;
+        if (l != 0) {
+            adj_f = on ? adj_f + adj_nu * (1. + eta * Qk[k]) : adj_f;
+            s_eta = on ? s_eta + adj_nu * f * Qk[k] : s_eta;
+            adj_fs = on ? adj_fs + adj_nu * (double)m : adj_fs;
+            s_a3 = on ? s_a3 + adj_nu * ck[k] : s_a3;
+        } else {
+            adj_f = on ? adj_f + adj_nu : adj_f;
         }
     }
+    BFINE(1);
     if (l != 0) { sh[SL_ETA] = s_eta; sh[SL_A3] = s_a3; }      // the slots were zero
     adj_W += 2.0 * W * adj_g2;
     if (C.asym != 0) {
@@ -120,14 +136,16 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
     } else {
         sh[SL_A1] += adj_fs;
     }
+    BFINE(2);
     // heights
     const double piW = PI * W;
     if (L.variant != 2) {
         // components below l carry no adjoint of their own: the sum over the components reduces to the +m ones
-        double adj_H = 0.0;
+        double adj_H = 0.0, rt[4];
 #pragma unroll
-        for (int am = 0; am <= 3; am++)
-            if (am <= l) adj_H += ah[am] * C.ratios[l][l + am];
+        for (int am = 0; am <= 3; am++) rt[am] = C.ratios[l][(l + am < TM_MAXM) ? l + am : TM_MAXM - 1];
+#pragma unroll
+        for (int am = 0; am <= 3; am++) adj_H = (am <= l) ? adj_H + ah[am] * rt[am] : adj_H;
         // ratio slot |m| collects the pair's adjoint; the slots were zero
 #pragma unroll
         for (int am = 0; am <= 3; am++)
@@ -150,6 +168,7 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
             }
         }
     }
+    BFINE(3);
     // width
     if (M.width_kind == 0) {
         pi[np] = M.idx_w0; pv[np] = tm_sign(M.Wraw) * adj_W; np++;
@@ -191,6 +210,7 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
         }
     }
     pi[np] = M.idx_f; pv[np] = adj_f; np++;
+    BFINE(4);
 }
 
 #ifndef TM_BW_THREADS
@@ -243,9 +263,9 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     const int ncp = TM_NCPAIR + (L.model_case == 9 ? (L.Nmax * (L.lmax + 2) + L.lmax) : 0);
     const int npairs_max = nm * TM_NPAIR + ncp;
     double *shared_adj = pair_val + npairs_max;                // [nm*TM_NSHARED]
-    double *s_G = shared_adj + (size_t)nm * TM_NSHARED;        // [nm*TM_GSLOTS] tile-summed partials
+    double *s_G = shared_adj + (size_t)nm * TM_NSHARED;        // [nm][TM_GSTRIDE] tile-summed partials
     const int npairs_pad = (npairs_max + 7) & ~7;              // the gather reads the pairs eight at a time
-    int *pair_idx = reinterpret_cast<int *>(s_G + (size_t)nm * TM_GSLOTS);  // [npairs_pad], moved up to a 16-byte boundary:
+    int *pair_idx = reinterpret_cast<int *>(s_G + (size_t)nm * TM_GSTRIDE);  // [npairs_pad], moved up to a 16-byte boundary:
     pair_idx += (4 - (((unsigned)(uintptr_t)pair_idx >> 2) & 3)) & 3;
     // per-multiplet records: staged in LDS when they fit (coalesced copy), else read in place from global
     constexpr int AUXD = (int)(sizeof(TmMultFull) / sizeof(double));
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
                         acc += gmult[(((size_t)chain * tiles + t) * nm + j) * TM_GSLOTS + sl];
             }
         }
-        s_G[item] = acc;
+        s_G[j * TM_GSTRIDE + sl] = acc;
     }
     __syncthreads();
     BW_TS(2, 0);
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
     BW_TS(14, 192);
     // phase 1b: chain rule, one thread per multiplet (tm_bw_mult above)
     for (int j = tid; j < nm; j += TM_BW_THREADS)
-        tm_bw_mult(L, &C, auxp + j, s_G + (size_t)j * TM_GSLOTS, p, shared_adj + (size_t)j * TM_NSHARED, pair_idx + j * TM_NPAIR,
+        tm_bw_mult(L, &C, auxp + j, s_G + (size_t)j * TM_GSTRIDE, p, shared_adj + (size_t)j * TM_NSHARED, pair_idx + j * TM_NPAIR,
                    pair_val + j * TM_NPAIR);
     __syncthreads();
     BW_TS(3, 0);
@@ -662,6 +682,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #ifdef TM_BW_TRACE
     __syncthreads();
     if (tid < 20 && tid < Nvars) grad[(size_t)chain * Nvars + tid] = (double)(long long)(s_ts[tid] - s_ts[0]);
+    if (tid < 5 && 20 + tid < Nvars) grad[(size_t)chain * Nvars + 20 + tid] = (double)(long long)(g_bfine[tid] - s_ts[0]);
 #endif
 }
 
@@ -676,7 +697,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int
     const int npairs_max = nm * TM_NPAIR + ncp;
     if (units < 1 || cells < 1 || tiles < 1) return (int)hipErrorInvalidValue;
     size_t lds = ((size_t)L.Nparams + (size_t)Nvars) * sizeof(double) + (size_t)npairs_max * sizeof(double) +
-                 (size_t)nm * (TM_NSHARED + TM_GSLOTS) * sizeof(double) + 16 + (size_t)((npairs_max + 7) & ~7) * sizeof(int) +
+                 (size_t)nm * (TM_NSHARED + TM_GSLOTS + 1) * sizeof(double) + 16 + (size_t)((npairs_max + 7) & ~7) * sizeof(int) +
                  (size_t)((tiles + 2) & ~1) * sizeof(int) + (size_t)((L.Nparams + 1) & ~1) * sizeof(int) +
                  (size_t)(TM_BW_THREADS / 64) * Nvars * sizeof(double);
     const size_t aux_bytes = (size_t)nm * sizeof(TmMultFull);

@@ -17,11 +17,13 @@ names = ["start", "staged", "gathered tiles", "per-multiplet chain rule", "chain
          "(t0) chain-level pairs done", "after barrier", "gather per variable done", "after barrier", "(t64) enter noise",
          "(t64) noise pairs done", "(t0) params + records staged", "(t64) noise partials summed", "(t192) logL finalized",
          "(t0) at the staging barrier", "(t0) kernel arguments arrived", "(t0) first load from memory back",
-         "(t0) second load, same line", "(t0) third load, another buffer"]
+         "(t0) second load, same line", "(t0) third load, another buffer",
+         "chain rule: entry", "chain rule: component sums done", "chain rule: asymmetry + splitting done", "chain rule: heights done",
+         "chain rule: width done"]
 with tamcmc_amd.Accel(w["model_case"], w["plength"], w["x"], y) as acc:
     acc.set_vars(w["index_to_relax"])
     for _ in range(20):
         L, st, g = acc.eval_batch(P, T, grad=True)
-    ts = np.median(g[:, :20], axis=0)
+    ts = np.median(g[:, :25], axis=0)
     for i, nm in enumerate(names):
         print(f"{i:2d} {nm:32s} {ts[i]:9.0f} cycles")
