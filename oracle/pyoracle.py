@@ -41,6 +41,13 @@ def lib():
                                          dp, dp, dp, ip, dp, C.c_int]
         L.orc_grad_fd.argtypes = [C.c_int, C.c_int, C.c_double, ip, C.c_long, dp, dp, dp, C.c_int, dp, C.c_double,
                                   C.c_int, ip, C.c_double, dp]
+        L.orc_grad_fd_wide.argtypes = L.orc_grad_fd.argtypes
+        L.orc_grad_analytic.argtypes = [C.c_int, C.c_int, C.c_double, ip, C.c_long, dp, dp, dp, C.c_int, dp, C.c_double,
+                                        C.c_int, ip, dp, dp, dp]
+        L.orc_grad_analytic_batch.argtypes = [C.c_int, C.c_int, C.c_double, ip, C.c_long, dp, dp, dp, C.c_int, C.c_int,
+                                              dp, dp, C.c_int, ip, dp, dp, dp, ip, C.c_int]
+        L.orc_amplitude_ratio_closed.argtypes = [C.c_int, C.c_double, dp, dp]
+        L.orc_amplitude_ratio_closed.restype = None
         L.orc_noise_harvey1985.argtypes = [dp, C.c_long, dp, dp, C.c_long, C.c_int]
         L.orc_noise_harvey1985.restype = None
         L.orc_max_threads.restype = C.c_int
@@ -120,6 +127,44 @@ def grad_fd(model_case, plength, x, y, params_row, Tcoef, index_to_relax, rel_st
     st = lib().orc_grad_fd(int(model_case), int(likelihood_case), float(likelihood_p), _i(pl), x.size, _d(x), _d(y),
                            _d(sig), p.size, _d(p), float(Tcoef), idx.size, _i(idx), float(rel_step), _d(g))
     return g, st
+
+
+def grad_fd_wide(model_case, plength, x, y, params_row, Tcoef, index_to_relax, rel_step=1e-6, sigma_y=None,
+                 likelihood_case=0, likelihood_p=1.0):
+    """Richardson central differences of the log-likelihood summed in long double (see orc_grad_fd_wide)."""
+    x, y, p = _f64(x), _f64(y), _f64(params_row)
+    sig = _f64(sigma_y) if sigma_y is not None else None
+    pl = np.ascontiguousarray(plength, dtype=np.int32)
+    idx = np.ascontiguousarray(index_to_relax, dtype=np.int32)
+    g = np.empty(idx.size)
+    st = lib().orc_grad_fd_wide(int(model_case), int(likelihood_case), float(likelihood_p), _i(pl), x.size, _d(x), _d(y),
+                                _d(sig), p.size, _d(p), float(Tcoef), idx.size, _i(idx), float(rel_step), _d(g))
+    return g, st
+
+
+def grad_analytic(model_case, plength, x, y, params, Tcoefs, index_to_relax, sigma_y=None, likelihood_case=0,
+                  likelihood_p=1.0, nthreads=0):
+    """Analytic d(logL/T)/dvars of the oracle for a batch of chains.
+    Returns (grad[n, Nvars], grad_abs[n, Nvars] = sum of |terms| of every entry, logL[n], status[n])."""
+    x, y, params, T = _f64(x), _f64(y), np.atleast_2d(_f64(params)), np.atleast_1d(_f64(Tcoefs))
+    sig = _f64(sigma_y) if sigma_y is not None else None
+    pl = np.ascontiguousarray(plength, dtype=np.int32)
+    idx = np.ascontiguousarray(index_to_relax, dtype=np.int32)
+    n, npar = params.shape
+    g = np.empty((n, idx.size))
+    ga = np.empty((n, idx.size))
+    logL = np.empty(n)
+    status = np.empty(n, dtype=np.int32)
+    lib().orc_grad_analytic_batch(int(model_case), int(likelihood_case), float(likelihood_p), _i(pl), x.size, _d(x), _d(y),
+                                  _d(sig), n, npar, _d(params), _d(T), idx.size, _i(idx), _d(g), _d(ga), _d(logL),
+                                  _i(status), int(nthreads))
+    return g, ga, logL, status
+
+
+def amplitude_ratio_closed(l, beta_rad):
+    v, d = np.empty(2 * l + 1), np.empty(2 * l + 1)
+    lib().orc_amplitude_ratio_closed(int(l), float(beta_rad), _d(v), _d(d))
+    return v, d
 
 
 def max_threads():
