@@ -258,7 +258,6 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_FUSED", 0, 1, &c->fuse);
     env_int("TAMCMC_EQUAL_COST", 0, 1, &c->equal_cost);
     env_int("TAMCMC_PRIO", 0, 1, &c->prio);
-    env_int("TAMCMC_PRIO", 0, 1, &c->prio);
     auto env_cost = [](const char *name, TmCostModel *m) {
         const char *e = getenv(name);
         int c0, a, b;
@@ -334,6 +333,11 @@ extern "C" int tamcmc_ctx_set_vars(tamcmc_ctx *c, int32_t Nvars, const int32_t *
     TM_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_relax); c->d_relax = nullptr;
     c->Nvars = Nvars;
+    // the asymmetry as a variable: its derivative does not vanish at asym == 0 although the factor is 1 there
+    c->L.asym_var = 0;
+    if (c->L.family != TM_FAM_GAUSS)
+        for (int i = 0; i < Nvars; i++)
+            if (index_to_relax[i] == c->L.s + 5) c->L.asym_var = 1;
     if (Nvars > 0) {
         TM_HIP(hipMalloc(&c->d_relax, (size_t)Nvars * sizeof(int32_t)));
         TM_HIP(hipMemcpy(c->d_relax, index_to_relax, (size_t)Nvars * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -510,7 +514,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.cells = cells; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
-    a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio; a.prio = c->prio;
+    a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio;
     if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     // one tile per chain (short grids): prologue and evaluation share a launch

@@ -113,11 +113,12 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
     BFINE(1);
     if (l != 0) { sh[SL_ETA] = s_eta; sh[SL_A3] = s_a3; }      // the slots were zero
     adj_W += 2.0 * W * adj_g2;
-    if (C.asym != 0) {
+    if (C.asym != 0 || L.asym_var != 0) {   // same predicate as the setup kernel's asymmetric path (the sums exist)
         const double al = C.asym;
         const double cc = 0.5 * W * al / f, c2 = cc * cc;
         const double C0 = G[21], C1 = G[22], C2 = G[23];
-        sh[SL_ASYM] += 2.0 * (C2 / f - C1) + (2.0 * c2 / al) * C0;
+        // dA/d(asym) = 2 a (x/f - 1) + asym W^2 / (2 f^2): regular at asym = 0, where A = 1 but the derivative is not 0
+        sh[SL_ASYM] += 2.0 * (C2 / f - C1) + (0.5 * W * W * al / (f * f)) * C0;
         adj_W += (2.0 * c2 / W) * C0;
         adj_f += -2.0 * al / (f * f) * C2 - (2.0 * c2 / f) * C0;
     }

@@ -45,6 +45,10 @@ struct TmLayout {
     int32_t likelihood_case;
     int32_t Nx;
     int32_t bg_exact;     // developer switch (env TAMCMC_BG_EXACT=1): no in-cell polynomials, exp() per bin and profile
+    int32_t asym_var;     // the asymmetry parameter (params[s+5]) is one of the gradient variables (tamcmc_ctx_set_vars):
+                          // the gradient launch then takes the asymmetric code path even where asym == 0 -- the factor
+                          // A(x) is 1 there, but dA/d(asym) = 2 (x/f - 1) is not
+    int32_t pad_l;
     double  x0, xlast, step;  // x[0], x[Nx-1], x[1]-x[0] (models.cpp:489)
     double  like_p;           // (double)(long)likelihood_params
 };

@@ -28,6 +28,8 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
                                               int *s_pre /* LDS, [units] when tiles > 1 and units <= TM_EQ_MAXU, else unused */)
 {
     __shared__ int s_win[TM_MAXMULT][3];   // truncation windows and component counts, for the per-tile active lists
+    // gradient launch with the asymmetry among the variables: asymmetric code path also where asym == 0 (TmLayout::asym_var)
+    const bool asym_forced = (L.asym_var != 0) && (chain_rec != nullptr);
     __shared__ __attribute__((aligned(16))) int s_cost[TM_ORDER_MAX + 4];
     const int tid = threadIdx.x;
 #ifdef TM_SU_TRACE
@@ -182,7 +184,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
         const int G = 1 << gshift, gpw = 64 >> gshift;                     // lanes per group, groups per wave
         const int g = lane >> gshift, gl = lane & (G - 1);
         const unsigned long long gmask = (G == 64) ? ~0ULL : ((1ULL << G) - 1ULL);
-        const int asym_bit = (C.asym != 0) ? 256 : 0;
+        const int asym_bit = (C.asym != 0 || asym_forced) ? 256 : 0;
         for (int t0 = wv * gpw; t0 < tiles; t0 += NW * gpw) {              // wave-uniform trip count: the ballots below need every lane
             const int tile = t0 + g;
             const bool live = tile < tiles;
@@ -258,7 +260,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
             TmMult out;
             const double g2 = M.W * M.W;
             out.g2 = g2;
-            if (C.asym == 0) {
+            if (C.asym == 0 && !asym_forced) {
                 out.aA = 0.0; out.aB = 1.0; out.c2 = 0.0; out.has_asym = 0;
             } else {
                 // A(x) = (1 + asym (x/f - 1))^2 + (0.5 Gamma asym / f)^2, build_lorentzian.cpp:96

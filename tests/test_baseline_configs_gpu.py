@@ -5,6 +5,7 @@ checked bit for bit).  HIP path against the CPU oracle; tolerances as in test_pa
 import numpy as np
 import pytest
 
+import gradcheck
 from tamcmc_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +41,9 @@ def test_c4_gradient_at_full_size(accel_mod, orc):
     assert np.max(np.abs(L - rL) / np.abs(rL)) <= RTOL_LOGL
     assert np.max(np.abs(L0 - rL) / np.abs(rL)) <= RTOL_LOGL
     assert np.all(np.isfinite(g)) and np.array_equal(g, g2) and np.array_equal(L, L2)
+    # (a') every one of the 16 x 94 entries, window on, against the oracle's analytic gradient (tests/gradcheck.py)
+    assert idx.size == 94
+    gradcheck.check_against_oracle(None, orc, 2, w, y, P, T, tag="C4 16 x 1e5, trunc_c 20", g=g)
 
     w = synth.workload_c4(trunc_c=10000.0)
     y = _spectrum(orc, w)
@@ -83,6 +87,7 @@ def test_c3_256_chains_one_batch_and_as_eight_blocks(accel_mod, orc):
     assert np.array_equal(np.concatenate([p[1] for p in parts]), st)
     assert np.array_equal(np.concatenate([p[0] for p in gparts]), Lg)
     assert np.array_equal(np.concatenate([p[2] for p in gparts]), g)
+    gradcheck.check_against_oracle(None, orc, 2, w, y, P, T, tag="C3 256 x 1e5", g=g)      # all 256 x 44 entries
 
 
 def test_c5_ensemble_32_stars_16_chains(accel_mod, orc):
@@ -113,6 +118,9 @@ def test_c5_ensemble_32_stars_16_chains(accel_mod, orc):
         assert np.max(np.abs(L[sel] - rL) / np.abs(rL)) <= RTOL_LOGL
         assert np.max(np.abs(Lg[sel] - rL) / np.abs(rL)) <= RTOL_LOGL
     assert np.all(np.isfinite(g))
+    for k in (0, 13, 31):               # gradient of three of the stars, entry by entry, against the oracle
+        sel = slice(k * nch, (k + 1) * nch)
+        gradcheck.check_against_oracle(None, orc, 2, w, Y[k], P[sel], T[sel], tag=f"C5 star {k}", g=g[sel])
     for k in (0, 7, 19, 31):
         sel = slice(k * nch, (k + 1) * nch)
         with accel_mod.Accel(2, w["plength"], w["x"], Y[k]) as one:

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import gradcheck
 import workloads as W
 from tamcmc_amd import synth
 
@@ -17,7 +18,8 @@ def test_random_configurations_match_the_oracle(accel_mod, orc, monkeypatch, bal
     monkeypatch.setenv("TAMCMC_EQUAL_COST", str(balanced))     # 1: per-chain tile boundaries from the setup kernel's balancer
     ncases = int(os.environ.get("TAMCMC_FUZZ_CASES", "60"))
     rng = np.random.default_rng(int(os.environ.get("TAMCMC_FUZZ_SEED", "1")) + 1000 * balanced)
-    worst_L = worst_M = worst_g = 0.0
+    worst_L = worst_M = worst_g = worst_c = worst_r = 0.0
+    an_done = 0
     done, failures = 0, []
     fd_done, fd_max = 0, max(8, ncases // 10)
     for case in range(ncases):
@@ -67,6 +69,18 @@ def test_random_configurations_match_the_oracle(accel_mod, orc, monkeypatch, bal
                 worst_M = max(worst_M, eM)
                 ok = ok and eM <= 1e-12
         ok = ok and bool(np.all(np.isnan(L[~good]) == np.isnan(rL[~good])))
+        # every gradient entry of every healthy chain against the oracle's analytic gradient (window on or off)
+        if ok and np.any(good):
+            ga_ref, ga_abs, _, ga_st = orc.grad_analytic(mid, w["plength"], w["x"], y, P[good], T[good], w["index_to_relax"],
+                                                         sigma_y=sig, likelihood_case=like)
+            try:
+                assert np.all(ga_st == 0)
+                ec, er = gradcheck.assert_grad_entrywise(g[good], ga_ref, ga_abs, tag=f"case {case}")
+                worst_c, worst_r = max(worst_c, ec), max(worst_r, er)
+                an_done += int(good.sum())
+            except AssertionError as e:
+                ok = False
+                failures.append(str(e))
         # gradient against Richardson-extrapolated central differences of the oracle, where logL is smooth (no
         # truncation window) and the grid is short enough for ~100 oracle evaluations
         if ok and good[0] and kw.get("trunc_c") == 10000.0 and Nx <= 3000 and fd_done < fd_max:
@@ -81,6 +95,7 @@ def test_random_configurations_match_the_oracle(accel_mod, orc, monkeypatch, bal
         if not ok:
             failures.append((case, mid, kw, n, like, st.tolist(), rst.tolist()))
     print(f"fuzz: {done} cases, worst relative logL error {worst_L:.2e}, model {worst_M:.2e}; {fd_done} gradients against "
-          f"finite differences, worst {worst_g:.2e} of the largest entry")
+          f"finite differences, worst {worst_g:.2e} of the largest entry; {an_done} gradient rows against the analytic oracle, "
+          f"worst entry {worst_c:.2e} of its sum|terms|, {worst_r:.2e} relative")
     assert not failures, failures
     assert done >= ncases // 2

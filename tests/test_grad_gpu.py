@@ -1,9 +1,13 @@
 """Gradient of the tempered log-likelihood (new functionality: the reference has none, MALA.cpp:18).
-Checked against Richardson-extrapolated central differences of the ORACLE log-likelihood with
-trunc_c = 10000 (no truncation window, so logL is smooth; SURVEY.md App. D caveat)."""
+Checked (a) ENTRY BY ENTRY against the oracle's analytic gradient (orc_grad_analytic: an independent statement of
+SURVEY.md App. D, itself pinned per entry against finite differences on the CPU, tests/test_oracle_grad.py) -- with the
+truncation window on, every model id, and at the benchmarked shape; tolerance in tests/gradcheck.py;
+(b) as in round 1/2 against Richardson-extrapolated central differences of the ORACLE log-likelihood with trunc_c = 10000
+(no truncation window, so logL is smooth; SURVEY.md App. D caveat), 2e-5 of the row's largest entry."""
 import numpy as np
 import pytest
 
+import gradcheck
 import workloads as W
 from tamcmc_amd import synth
 
@@ -47,6 +51,72 @@ def test_gradient_vs_finite_differences(accel_mod, orc, mid, kw):
     m, st = orc.model(mid, w["params_true"], w["plength"], w["x"])
     y = synth.make_spectrum(m, seed=23)
     fd_check(accel_mod, orc, mid, w, y)
+
+
+def _all_shape_variables(w, mid):
+    """eta, a3 and the asymmetry join the variables (fixed in the synthetic star's .model)."""
+    relax = w["relax"].copy()
+    pl = w["plength"]
+    s = int(pl[0] + pl[1] + pl[2:6].sum())
+    relax[[s + 1, s + 2, s + 5]] = 1
+    w["relax"] = relax
+    w["index_to_relax"] = np.flatnonzero(relax).astype(np.int32)
+    return w
+
+
+@pytest.mark.parametrize("mid", [2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("kw", [dict(trunc_c=20.0), dict(trunc_c=7.0, asym=-40.0, do_amp=True), dict(trunc_c=20.0, asym=25.0),
+                                dict(trunc_c=10000.0, do_amp=True)],
+                         ids=["c20", "c7-asym-amp", "c20-asym", "notrunc-amp"])
+def test_gradient_entrywise_vs_oracle_analytic(accel_mod, orc, mid, kw):
+    """Every live Lorentzian model id, truncation window ON (trunc_c 20 and 7) and off, all variables incl. eta, a3 and
+    asymmetry, 5000 bins (not a multiple of any tile size), 6 tempered chains: every entry against orc_grad_analytic."""
+    w = _all_shape_variables(W.any_model(mid, Nx=5000, **kw), mid)
+    m, st = orc.model(mid, w["params_true"], w["plength"], w["x"])
+    assert st == 0
+    y = synth.make_spectrum(m, seed=17)
+    P = W.perturbed(w, 6, scale=0.004)
+    T = synth.temperatures(6)
+    with accel_mod.Accel(mid, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        gradcheck.check_against_oracle(acc, orc, mid, w, y, P, T, tag=f"id {mid} {kw}")
+
+
+@pytest.mark.parametrize("mid", [0, 1, 2, 11])
+def test_gradient_entrywise_chi_square_and_p(accel_mod, orc, mid):
+    """chi_square likelihood (likelihoods.cpp:31-39) and a truncated likelihood exponent p = 2.9 -> 2 (model_def.cpp:300)."""
+    w = W.any_model(mid, Nx=3000)
+    if mid in (2, 11):
+        w = _all_shape_variables(w, mid)
+    m, _ = orc.model(mid, w["params_true"], w["plength"], w["x"])
+    y = synth.make_spectrum(m, seed=19)
+    sig = 0.05 + 0.2 * np.abs(np.sin(np.arange(y.size)))
+    P = W.perturbed(w, 4, scale=0.003)
+    T = synth.temperatures(4)
+    with accel_mod.Accel(mid, w["plength"], w["x"], y, sigma_y=sig, likelihood_case=1) as acc:
+        acc.set_vars(w["index_to_relax"])
+        gradcheck.check_against_oracle(acc, orc, mid, w, y, P, T, sigma=sig, like=1, tag=f"id {mid} chi_square")
+    with accel_mod.Accel(mid, w["plength"], w["x"], y, likelihood_p=2.9) as acc:
+        acc.set_vars(w["index_to_relax"])
+        gradcheck.check_against_oracle(acc, orc, mid, w, y, P, T, likelihood_p=2.9, tag=f"id {mid} p=2.9")
+
+
+@pytest.mark.parametrize("mid", [2, 3])
+def test_gradient_entrywise_c2_full_size(accel_mod, orc, mid):
+    """BASELINE config C2 -- the benchmarked shape: 64 tempered chains x 1e5 bins, trunc_c = 20, all 44 (id 2) variables,
+    every one of the 64 x 44 entries against the oracle's analytic gradient; logL of the gradient path vs the oracle."""
+    w = synth.workload_c2(model_case=mid)
+    m, _ = orc.model(mid, w["params_true"], w["plength"], w["x"])
+    y = synth.make_spectrum(m)
+    P = synth.chain_params(w, 64)
+    T = synth.temperatures(64)
+    with accel_mod.Accel(mid, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        L, st, g = acc.eval_batch(P, T, grad=True)
+    assert np.all(st == 0)
+    rL, rst = orc.generate_batch(mid, w["plength"], w["x"], y, P, T)
+    assert np.max(np.abs(L - rL) / np.abs(rL)) <= 1e-10
+    gradcheck.check_against_oracle(None, orc, mid, w, y, P, T, tag=f"C2 id {mid}", g=g)
 
 
 @pytest.mark.parametrize("mid", [0, 1])
@@ -106,6 +176,8 @@ def test_gradient_on_polynomial_background_tiles(accel_mod, orc, monkeypatch):
     scale = np.max(np.abs(g1), axis=1, keepdims=True)
     assert np.max(np.abs(g0 - g1) / scale) < 1e-11
     assert not np.array_equal(g0, g1)      # the two paths really are different code
+    for g_path, name in ((g0, "moments"), (g1, "exact")):      # both against the oracle, entry by entry, at full size
+        gradcheck.check_against_oracle(None, orc, 2, w, y, P, T, tag=f"background {name}", g=g_path)
 
 
 def test_gradient_requires_vars(accel_mod, orc):

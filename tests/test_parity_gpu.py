@@ -9,6 +9,7 @@ seeded inputs.  Tolerances (written here once):
 import numpy as np
 import pytest
 
+import gradcheck
 import workloads as W
 from tamcmc_amd import synth
 
@@ -237,6 +238,7 @@ def test_large_grid_and_many_chains(accel_mod, orc):
     check_logL(logL, rL)
     check_logL(logLg, rL)
     assert np.all(np.isfinite(g))
+    gradcheck.check_against_oracle(None, orc, 2, w, y, P, T, tag="Nx = 1e6", g=g)
     w2 = synth.workload_c2(Nx=20000)
     y2 = spectrum_for(orc, w2)
     P2 = synth.chain_params(w2, 256)
@@ -362,6 +364,7 @@ def test_more_than_64_multiplets(accel_mod, orc):
     assert np.array_equal(st, rst) and np.array_equal(stg, rst)
     check_logL(L, rL)
     check_logL(Lg, rL)
+    gradcheck.check_against_oracle(None, orc, 2, w, y, P, T, tag="80 multiplets, 136 variables", g=g)
     # a few gradient entries against central differences of the oracle (all variables would take minutes)
     idx = w["index_to_relax"]
     pick = idx[[0, 21, 45, 80, idx.size - 12, idx.size - 1]]
