@@ -515,6 +515,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.cells = cells; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
     a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio;
+    a.generic = (c->L.likelihood_case != 0 || c->L.family == TM_FAM_GAUSS || d_rows != nullptr) ? 1 : 0;
     if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     // one tile per chain (short grids): prologue and evaluation share a launch

@@ -150,7 +150,7 @@ struct TmEvalArgs {
     const int32_t *order;       // [Nchains][tiles] launch rank -> tile, costliest first (setup kernel), or NULL
     int32_t order_mode;
     int32_t prio;               // 1: issue priority by launch rank (s_setprio), 0: all workgroups alike
-    int32_t pad0;
+    int32_t generic;            // 0: chi(2,2p), no Gaussian term, no model rows -> the specialised eval kernel (tamcmc_eval_body.h, GEN)
     double like_p;
     unsigned long long tile_magic;   // ceil(2^40 / tiles): n / tiles == (n * tile_magic) >> 40 for n < 2^20 (slot -> tile rotation)
 };

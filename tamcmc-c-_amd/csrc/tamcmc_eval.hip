@@ -43,7 +43,7 @@
 
 #include "tamcmc_eval_body.h"
 
-template <bool GRAD>
+template <bool GRAD, bool GEN>
 __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
 {
     TM_STAMP(0);
@@ -65,12 +65,12 @@ __global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void t
     // Issue priority by launch rank: the costliest quarter of a chain's tiles runs at priority 3, the next at 2, 1, 0.
     // Waves are served oldest-first anyway; this keeps a late-placed cheap workgroup from slowing the long ones it
     // joins (measured: the opposite assignment costs 4 %, this one gains ~1 %; profiles/README.md).
-    if (a.order_mode != 0 && a.prio != 0) {
+    if (a.order_mode != 0 && a.prio == 1) {
         const int r4 = (4 * (int)blockIdx.y) / a.tiles;
         if (r4 == 0) __builtin_amdgcn_s_setprio(3); else if (r4 == 1) __builtin_amdgcn_s_setprio(2); else if (r4 == 2) __builtin_amdgcn_s_setprio(1);
     }
     extern __shared__ double s_dyn[];                                // weights of pass 2: [TM_TILE_MAXU * TM_UNIT_BINS]   (GRAD only)
-    tm_eval_body<GRAD>(a, chain, tile, s_dyn);
+    tm_eval_body<GRAD, GEN>(a, chain, tile, s_dyn);
 }
 
 int tm_launch_eval(const TmEvalArgs &a, int Nchains, bool grad, void *stream_)
@@ -92,8 +92,11 @@ int tm_launch_eval(const TmEvalArgs &a, int Nchains, bool grad, void *stream_)
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tm_trace), &d_trace, sizeof(d_trace), 0, hipMemcpyHostToDevice, stream);
     }
 #endif
-    if (grad) hipLaunchKernelGGL((tamcmc_eval_kernel<true>), grid, block, lds, stream, a);
-    else      hipLaunchKernelGGL((tamcmc_eval_kernel<false>), grid, block, lds, stream, a);
+    const bool gen = a.generic != 0;
+    if (grad && gen)       hipLaunchKernelGGL((tamcmc_eval_kernel<true, true>), grid, block, lds, stream, a);
+    else if (grad)         hipLaunchKernelGGL((tamcmc_eval_kernel<true, false>), grid, block, lds, stream, a);
+    else if (gen)          hipLaunchKernelGGL((tamcmc_eval_kernel<false, true>), grid, block, lds, stream, a);
+    else                   hipLaunchKernelGGL((tamcmc_eval_kernel<false, false>), grid, block, lds, stream, a);
 #ifdef TM_TRACE
     if (tf && grad == trace_grad) {
         (void)hipStreamSynchronize(stream);

@@ -20,6 +20,13 @@ typedef const __attribute__((address_space(4))) TmNoise *TmNoiseK;
 typedef const __attribute__((address_space(4))) int32_t *TmIdxK;
 typedef const __attribute__((address_space(4))) TmActive *TmActiveK;
 
+// One entry of a tile's active list as ONE 16-byte scalar load (s_load_dwordx4): {idx, imin, imax, shape}.
+typedef int TmEntry __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ TmEntry tm_load_entry(TmActiveK p)
+{
+    return *reinterpret_cast<const __attribute__((address_space(4))) TmEntry *>(p);
+}
+
 // 1/x for finite, normal, positive x: v_rcp_f64 + two Newton steps (no scaling / fix-up needed
 // because every denominator here is bounded away from the subnormal and overflow ranges).
 __device__ __forceinline__ double tm_rcp(double x)
@@ -400,9 +407,12 @@ template <bool B> struct TmBool { static constexpr bool value = B; };
 // inside the grid takes the FULL path: no index clamps, no per-bin validity tests, loads at constant offsets from one
 // per-thread pointer; within it a multiplet whose window covers the whole group takes the no-test form of
 // tm_accum_mult.  Only the grid's last, partial unit takes the guarded path.
-template <bool GRAD>
+// GEN = false: the common case compiled on its own -- chi(2,2p) likelihood, no Gaussian term (ids 0, 1), no model rows
+// requested; the launcher picks it from the context (TmEvalArgs::generic).  Same arithmetic, fewer live scalars.
+template <bool GRAD, bool GEN = true>
 __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chain, const int tile, double *s_w)
 {
+    const int like = GEN ? a.likelihood_case : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     TmNoiseK sn = (TmNoiseK)(a.noise + chain);
@@ -430,9 +440,9 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     TmCellRecK cells = (TmCellRecK)(a.cell + (size_t)chain * a.cells);
     TmActiveK tix = (TmActiveK)(a.tidx + ((size_t)chain * a.tiles + tile) * (a.n_mult > 0 ? a.n_mult : 1));
     const int nh = sn->nh;
-    const bool has_gauss = sn->has_gauss != 0;
+    const bool has_gauss = GEN && sn->has_gauss != 0;
     const double N0 = sn->N0;
-    const int row = (a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
+    const int row = (GEN && a.row_of_chain != nullptr) ? a.row_of_chain[chain] : -1;
     // FULL groups address the grid as (wave-uniform base pointer) + (32-bit per-thread bin index): global loads with a
     // scalar base and one VGPR of offset, instead of one 64-bit pointer per array and thread (Nx < 2^28 is checked at create)
     const double *__restrict__ xb = a.x2;
@@ -479,11 +489,28 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
 #pragma unroll
             for (int k = 0; k < KG; k++) { lxe[k] = (nh > 0) ? lb[(unsigned)bi[k]] : 0.0; ye[k] = yp[(unsigned)bi[k]]; }
         }
-        for (int jj = 0; jj < nact; jj++) {
-            const int idx = tix[jj].idx, imin = tix[jj].imin, imax = tix[jj].imax, shape = tix[jj].shape;   // one 16-byte scalar load
-            if (hi <= imin || lo >= imax) continue;   // wave-uniform skip
-            tm_accum_dispatch<KG>((TmMultK)(gm + idx), shape, x2, bi, acc, !(FULL && lo >= imin && hi <= imax));
+        if constexpr (GRAD) {
+            for (int jj = 0; jj < nact; jj++) {
+                const int idx = tix[jj].idx, imin = tix[jj].imin, imax = tix[jj].imax, shape = tix[jj].shape;
+                if (hi <= imin || lo >= imax) continue;   // wave-uniform skip
+                tm_accum_dispatch<KG>((TmMultK)(gm + idx), shape, x2, bi, acc, !(FULL && lo >= imin && hi <= imax));
+            }
+        } else if (nact > 0) {
+            // Likelihood kernel (SGPRs to spare): the list entry of the NEXT multiplet is requested before the current one
+            // is evaluated (one 16-byte scalar load, in flight beside the record's), so a wave waits once per multiplet
+            // instead of three times in a row (window; index and shape; record) -- waits that a wave with few
+            // neighbours on its SIMD cannot hide (the tail of a launch).
+            TmEntry e = tm_load_entry(tix);
+            asm volatile("" :: "s"(e.x));             // a use: the first entry is waited for here, not inside the loop
+            for (int jj = 0; jj < nact; jj++) {
+                const TmEntry en = tm_load_entry(tix + (jj + 1 < nact ? jj + 1 : jj));
+                const int idx = e.x, imin = e.y, imax = e.z, shape = e.w;
+                if (!(hi <= imin || lo >= imax))   // wave-uniform skip
+                    tm_accum_dispatch<KG>((TmMultK)(gm + idx), shape, x2, bi, acc, !(FULL && lo >= imin && hi <= imax));
+                e = en;
+            }
         }
+
         // background, likelihood and (GRAD) weights + noise partial sums, KH bins at a time: the gradient kernel keeps
         // three accumulators per component in pass 2 and sixteen noise sums here, so it takes the four bins of a group
         // in two halves (fewer values live at once: 4 waves per SIMD instead of 3)
@@ -547,7 +574,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
         }
 
         double wreg[GRAD ? KH : 1];
-        if (a.likelihood_case == 0) {
+        if (like == 0) {
             // -p * (sum y/M + sum log M), likelihoods.cpp:23-25
 #pragma unroll
             for (int k = 0; k < KH; k++) {
@@ -684,7 +711,7 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
     TM_STAMP(1);
     // tile partials: S1 = sum y/M (or the chi-square sum), and sum log M as (mantissa product, exponent sum)
     double Pm = 1.0, Pe = 0.0;
-    if (a.likelihood_case == 0) {
+    if (like == 0) {
         int e;
         Pm = frexp(tm_wave_prod(P), &e);
         Pe = tm_wave_sum((double)esum) + (double)e;
@@ -726,8 +753,8 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
                 // the chain's only tile: nothing to hand over.  Same value as the general path below, without its
                 // store-drain-ticket-reload round trip
                 pp[0] = t1; pp[1] = tm; pp[2] = te;
-                const double t2 = (a.likelihood_case == 0) ? tm_tile_logsum(tm, te) : 0.0;
-                double f = (a.likelihood_case == 0) ? -a.like_p * (t1 + t2) : -t1;
+                const double t2 = (like == 0) ? tm_tile_logsum(tm, te) : 0.0;
+                double f = (like == 0) ? -a.like_p * (t1 + t2) : -t1;
                 f = f / a.wt[2 * chain];
                 int st = a.noise[chain].status;
                 if (st != 0) f = __builtin_nan("");
@@ -749,14 +776,14 @@ __device__ __forceinline__ void tm_eval_body(const TmEvalArgs &a, const int chai
             double s1 = 0.0, s2 = 0.0;
             for (int t = lane; t < a.tiles; t += 64) {
                 s1 += __hip_atomic_load(pp + 4 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.likelihood_case == 0)
+                if (like == 0)
                     s2 += tm_tile_logsum(__hip_atomic_load(pp + 4 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                                          __hip_atomic_load(pp + 4 * t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
             s1 = tm_wave_sum(s1);
             s2 = tm_wave_sum(s2);
             if (lane == 0) {
-                double f = (a.likelihood_case == 0) ? -a.like_p * (s1 + s2) : -s1;
+                double f = (like == 0) ? -a.like_p * (s1 + s2) : -s1;
                 f = f / a.wt[2 * chain];
                 int st = a.noise[chain].status;
                 if (st != 0) f = __builtin_nan("");
