@@ -77,7 +77,9 @@ typedef struct tamcmc_ctx tamcmc_ctx;
  *                    `long p` argument (likelihoods.cpp:17).
  *   plength          the 11 block lengths of the params row.
  *   x, y, sigma_y    Nx doubles each on the host; sigma_y may be NULL unless likelihood_case == 1.
- *                    x must be the regular grid the reference assumes (build_lorentzian.cpp:423). */
+ *                    x must be the regular grid the reference assumes (build_lorentzian.cpp:423).
+ *   Nx               2 <= Nx <= 2^28 (TAMCMC_E_INVALID outside): the kernels address the grid with 32-bit byte
+ *                    offsets; the reference itself reads at most 1e6 rows (config.cpp:531). */
 int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case, int likelihood_case,
                       double likelihood_p, const int32_t plength[11], int64_t Nx,
                       const double *x, const double *y, const double *sigma_y);
@@ -151,7 +153,9 @@ int tamcmc_ctx_kernel_time(tamcmc_ctx *ctx, double *total_ms, int64_t *launches)
 int tamcmc_ctx_clock_probe_begin(tamcmc_ctx *ctx, double milliseconds);
 int tamcmc_ctx_clock_probe_end(tamcmc_ctx *ctx, double *core_GHz, double *seconds);
 
-/* Launch geometry actually used (for DESIGN.md / bench bookkeeping). */
+/* Launch geometry actually used (for DESIGN.md / bench bookkeeping): bins_per_tile = the largest tile of the
+ * likelihood-only launch (16 units of 512 bins; 8 when TAMCMC_EQUAL_COST balances the tiles, and always for the gradient
+ * launch), tiles = tiles per chain of the most recent likelihood-only call. */
 int tamcmc_ctx_geometry(tamcmc_ctx *ctx, int32_t *bins_per_tile, int32_t *tiles, int32_t *threads_per_block,
                         int32_t *n_multiplets);
 

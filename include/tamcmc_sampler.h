@@ -106,7 +106,12 @@ int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, i
  * RCCL on GPUs, gloo in the CPU tests; tamcmc-c-_amd/sharded.py); it returns 0 or non-zero on failure.  Processes that
  * own neither end do not communicate.  moved_hist / swap_hist as in tamcmc_sampler_run, except that an attempt this
  * process took no part in is recorded as -2.  With a block (below) the loop stops early when the block is full; *done
- * (may be NULL) receives the number of iterations completed, also when the call returns an error. */
+ * (may be NULL) receives the number of iterations completed, also when the call returns an error.
+ * Errors: the call returns at once when the evaluator, a swap step or the exchange fails on THIS process; it cannot go on
+ * answering its neighbours (the random stream of the failed iteration is spent, its chains have no state to send), so a
+ * neighbour that reaches a boundary pair with it would wait in its send/recv.  The caller must therefore take the whole
+ * process group down on a non-zero return (tamcmc-c-_amd/sharded.py does: it aborts the group, the peers' pending
+ * send/recv fail and they raise in turn); a rank must not simply leave the loop and idle. */
 typedef int (*tamcmc_exchange_fn)(void *user, int32_t my_chain, int32_t peer_chain, const double *send, double *recv,
                                   int32_t n_doubles);
 typedef struct tamcmc_shard_block tamcmc_shard_block;

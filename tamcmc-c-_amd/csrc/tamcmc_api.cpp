@@ -261,7 +261,11 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     auto env_cost = [](const char *name, TmCostModel *m) {
         const char *e = getenv(name);
         int c0, a, b;
-        if (e && sscanf(e, "%d,%d,%d", &c0, &a, &b) == 3 && c0 >= 1 && c0 <= 10000 && a >= 0 && a <= 1000 && b >= 0 && b <= 1000) { m->c0 = c0; m->a = a; m->b = b; }
+        // accepted only while the balancer's int32 cost prefix cannot overflow: the worst unit costs
+        // c0 + TM_MAXMULT * (7 a + b) and at most TM_EQ_MAXU units are balanced (tm_tile_bound itself works in 64 bit);
+        // a model outside that range is ignored (the defaults stay) rather than clamped
+        if (e && sscanf(e, "%d,%d,%d", &c0, &a, &b) == 3 && c0 >= 1 && c0 <= 10000 && a >= 0 && a <= 1000 && b >= 0 && b <= 1000 &&
+            ((long long)c0 + (long long)TM_MAXMULT * (7LL * a + b)) * (long long)TM_EQ_MAXU < (1LL << 31)) { m->c0 = c0; m->a = a; m->b = b; }
     };
     env_cost("TAMCMC_COST", &c->cost_l);
     env_cost("TAMCMC_COST_GRAD", &c->cost_g);
@@ -480,7 +484,7 @@ extern "C" int tamcmc_ctx_geometry(tamcmc_ctx *c, int32_t *bins_per_tile, int32_
 {
     if (!c) return TAMCMC_E_INVALID;
     const int T = c->last_tiles > 0 ? c->last_tiles : pick_tiles(c, 64, false);
-    if (bins_per_tile) *bins_per_tile = TM_UNIT_BINS * TM_TILE_MAXU;   // the largest tile the balancer can make
+    if (bins_per_tile) *bins_per_tile = TM_UNIT_BINS * c->cost_l.pad;   // largest tile of the likelihood launch (TM_TILE_MAXU_L units; TM_TILE_MAXU when balanced, and always for the gradient launch)
     if (tiles) *tiles = T;
     if (threads_per_block) *threads_per_block = TM_THREADS;
     if (n_multiplets) *n_multiplets = c->L.n_mult;
@@ -519,7 +523,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
     // one tile per chain (short grids): prologue and evaluation share a launch
-    const bool fused = (tiles == 1) && c->fuse != 0;
+    const bool fused = (tiles == 1) && c->fuse != 0 && units <= TM_TILE_MAXU;   // (TAMCMC_TILES=1 on a 9..16-unit grid: two launches)
     int rc = 0;
     if (!fused) {
         rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, units, cells, tiles, c->equal_cost, grad ? c->cost_g : c->cost_l,

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         rk = sid;
         rv = (sid < Nvars) ? relax[sid] : -1;
         for (int e = sid; e < L.Nparams; e += NS) s_inv[e] = -1;
-        for (int e = sid; e < npairs_pad; e += NS) { pair_idx[e] = -1; if (e < npairs_max) pair_val[e] = 0.0; }   // (index padding: the gather reads up to 7 values past the table, out of the next one, and drops them)
+        for (int e = sid; e < npairs_pad; e += NS) { pair_idx[e] = -1; if (e < npairs_max) pair_val[e] = 0.0; }   // (index padding: the ballot gather reads whole 64-pair chunks; the pad entries match no variable)
         for (int e = sid; e < nm * TM_NSHARED; e += NS) shared_adj[e] = 0.0;
 #pragma unroll
         for (int k = 0; k < KP; k++) { const int e = sid + k * NS; if (e < L.Nparams) p[e] = rp[k]; }
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
         double s1 = 0.0, s2 = 0.0;
         for (int t = lane; t < tiles; t += 64) {
             s1 += pp[4 * t];
-            if (L.likelihood_case == 0) s2 += log(pp[4 * t + 1]) + pp[4 * t + 2] * 0.693147180559945309417232;
+            if (L.likelihood_case == 0) s2 += tm_tile_logsum(pp[4 * t + 1], pp[4 * t + 2]);
         }
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
         if (lane == 0) {

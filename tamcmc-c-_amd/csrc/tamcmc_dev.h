@@ -172,6 +172,11 @@ static inline int tm_tiles(int units, int grad)
 }
 
 #if defined(__HIPCC__)
+// sum of log M over a tile from its (mantissa product, exponent sum): log(mant) + e ln 2 with ONE rounding of the
+// product-sum (explicit fma), so that the likelihood launch's in-launch finalize (tamcmc_eval_body.h, contracted build)
+// and the gradient path's finalize in the backward kernel (built with -ffp-contract=off) give the same bits.
+#define TM_LN2 0.693147180559945309417232
+static __device__ __forceinline__ double tm_tile_logsum(double mant, double e) { return __builtin_fma(e, TM_LN2, log(mant)); }
 #define TM_HD __host__ __device__
 #else
 #define TM_HD
@@ -191,7 +196,8 @@ static inline TM_HD int tm_setup_balances(int units, int tiles, int equal_cost, 
 // of cost(u) + lambda and lambda >= 0 is the uniform surcharge that keeps every tile within S = TM_TILE_MAXU units:
 // with D = T S - U (> 0 by the tile count) and N = max(0, C - T S cmin), lambda = N / D gives
 //     (tile size - 1) * (cmin + lambda) < (C + lambda U) / T = S (cmin + lambda),   i.e. size <= S.
-// Integer arithmetic throughout (cross-multiplied, 64 bit: T <= 1024, D <= 8192, C < 2^31 / T), so the boundaries are
+// Integer arithmetic throughout (cross-multiplied in 64 bit: T <= 2^10, D <= 2^13, C < 2^31 -- the int32 prefix; the
+// accepted cost models keep it there, tamcmc_api.cpp: env_cost -- so every product stays below 2^55), so the boundaries are
 // a pure function of the costs.  Shared by the setup kernel and tests/cpp/geometry_check.cpp.
 static inline TM_HD int tm_tile_bound(int t, int tiles, int units, const int *pre, long long C, long long cmin)
 {

@@ -11,8 +11,10 @@
 //
 // Mapping to gfx950 (wave64):
 //   grid = (chains, tiles), tile-major and costliest-first; workgroup = 256 threads = 4 waves.  The grid is cut into
-//   units of 512 bins; a tile is a run of at most 8 consecutive units whose bounds the setup kernel chose PER CHAIN so
-//   that all tiles of a chain cost about the same (tamcmc_dev.h, tamcmc_setup_body.h).  Thread t owns bins
+//   units of 512 bins; a tile is a run of consecutive units (at most 8 on the gradient path, 16 on the likelihood path)
+//   -- tiles of EQUAL LENGTH by default (25 per chain at 1e5 bins); with TAMCMC_EQUAL_COST=1 the setup kernel instead
+//   chooses a chain's bounds so that its tiles cost about the same (tamcmc_dev.h, tamcmc_setup_body.h; measured: no
+//   faster).  Thread t owns bins
 //   unit*512 + k*256 + t, so every global load is a coalesced 8-byte-per-lane stream (x, y, log x: 24 B per bin; the
 //   2.4 MB working set of a 1e5-bin star stays in L2).  Four bins per thread are processed together (instruction-level
 //   parallelism across the reciprocal's latency); the group loop is NOT unrolled, so the register footprint is set by

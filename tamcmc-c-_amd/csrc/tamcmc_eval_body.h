@@ -129,8 +129,7 @@ __device__ __forceinline__ double tm_wave_prod(double v)   // product over the 6
 // sum of log M over a tile, kept as (mantissa product, exponent sum): sum log M = log(mant) + e ln 2.  The product of the
 // 64 lanes' running mantissas (each in [0.5, 1): at least 2^-64, no underflow) and then of the 4 waves' replaces a log per
 // thread; the logs are taken once per tile by whoever sums the tiles (tm_tile_logsum).
-#define TM_LN2 0.693147180559945309417232
-__device__ __forceinline__ double tm_tile_logsum(double mant, double e) { return log(mant) + e * TM_LN2; }
+// (tm_tile_logsum: tamcmc_dev.h, shared with the backward kernel)
 
 // Horner evaluation of the cell's background polynomial; the coefficients are SGPR operands (scalar loads)
 __device__ __forceinline__ double tm_poly(TmCellRecK tr, double z)

@@ -25,6 +25,20 @@ def _gather(dist, arr, rank, world, device):
     return np.stack([o.cpu().numpy() for o in out])
 
 
+def _abort_group(dist):
+    """Best effort: close this rank's side of the process group at once (peers blocked on it then fail fast)."""
+    try:
+        pg = dist.distributed_c10d._get_default_group()
+        if hasattr(pg, "abort"):
+            pg.abort()
+        elif hasattr(pg, "_shutdown"):
+            pg._shutdown()
+        else:
+            dist.destroy_process_group()
+    except Exception:       # noqa: BLE001 -- we are already on an error path
+        pass
+
+
 def run_phase_sharded(setup, evaluator, dist, rank, world, seed, device=None, restore_precision=6, progress=None):
     """Restore (if configured) -> init -> iterate to Outputs.Nsamples; rank 0 writes the result and restore files.
     `evaluator`: this rank's Accel (or a callable for CPU tests).  Returns the local Sampler (state after the run)."""
@@ -91,7 +105,13 @@ def run_phase_sharded(setup, evaluator, dist, rank, world, seed, device=None, re
     while i < Nsamples:
         if progress is not None and rank == 0:
             progress(i, Nsamples)
-        done, _, _ = smp.run_sharded(min(cap, Nsamples - i), exchange, block=block)
+        try:
+            done, _, _ = smp.run_sharded(min(cap, Nsamples - i), exchange, block=block)
+        except Exception:
+            # a failed rank cannot answer its neighbours any more (include/tamcmc_sampler.h): take the group down so
+            # that their pending send / recv fail and they raise too, instead of waiting for the backend's timeout
+            _abort_group(dist)
+            raise
         i += done
         flush()
     block.close()

@@ -431,3 +431,44 @@ def test_fused_small_grid_launch_equals_two_launches(accel_mod, orc, monkeypatch
     assert np.array_equal(res[0][1], rst)
     check_logL(res[0][0], rL)
     check_logL(res[0][2], rL)
+
+
+def test_one_tile_by_hand_on_a_grid_longer_than_the_fused_kernel(accel_mod, orc, monkeypatch):
+    """TAMCMC_TILES=1 on a grid of 9..16 units (4609..8192 bins): one likelihood tile per chain is legal there (tiles of up
+    to 16 units) but the fused setup + evaluation launch holds at most 8 units -- the call must take the two-launch
+    path (it used to return TAMCMC_E_HIP), same logL as the default geometry to rounding; logL and gradient of the gradient path too."""
+    w = W.make(2, Nx=6000)                    # 12 units
+    y = spectrum_for(orc, w)
+    P = W.perturbed(w, 5, scale=0.003)
+    T = synth.temperatures(5)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        L0, st0 = acc.eval_batch(P, T)
+        Lg0, _, g0 = acc.eval_batch(P, T, grad=True)
+    monkeypatch.setenv("TAMCMC_TILES", "1")
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        L1, st1 = acc.eval_batch(P, T)
+        assert acc.geometry()["tiles"] == 1
+        Lg1, _, g1 = acc.eval_batch(P, T, grad=True)
+    rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+    assert np.array_equal(st1, rst) and np.array_equal(st0, rst)
+    check_logL(L1, rL)
+    check_logL(L0, rL)
+    assert np.array_equal(Lg0, Lg1) and np.array_equal(g0, g1)      # the gradient launch's tiles are not touched by TAMCMC_TILES
+
+
+def test_likelihood_and_gradient_paths_return_the_same_logL_bits(accel_mod, orc, monkeypatch):
+    """With the same tile geometry the in-launch finalize of the likelihood kernel and the backward kernel's finalize add
+    the same partials in the same order with the same arithmetic (tm_tile_logsum, tamcmc_dev.h): identical bits."""
+    w = synth.workload_c2(Nx=30000)
+    y = spectrum_for(orc, w)
+    P = synth.chain_params(w, 7)
+    T = synth.temperatures(7)
+    monkeypatch.setenv("TAMCMC_TILES", "10")
+    monkeypatch.setenv("TAMCMC_TILES_GRAD", "10")
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.set_vars(w["index_to_relax"])
+        L, st = acc.eval_batch(P, T)
+        Lg, stg, g = acc.eval_batch(P, T, grad=True)
+    assert np.all(st == 0) and np.array_equal(L, Lg)
