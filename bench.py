@@ -21,6 +21,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with, besides th
   sampler_sharded -- the same loop with 64*N chains sharded over the N ranks, parallel tempering every iteration,
                      boundary pairs exchanged between neighbours (RCCL send/recv), loop in C++
                      (tamcmc_sampler_run_sharded); reports the replicated random-stream term per iteration.
+  ensemble        -- BASELINE config C5: 32 independent synthetic stars x 16 chains, 32/N stars per rank held in ONE
+                     multi-spectrum context (tamcmc_ctx_set_spectra), no communication in the timed region, one
+                     max-over-ranks time (what the reference does with a Slurm array over stars,
+                     scripts/slurm/job_array.sh:8,24) -- strong scaling: the 32 stars are fixed, N divides them.
   cpu_baseline    -- the CPU oracle (OpenMP over chains like MALA.cpp:632) on this box's host cores, logL only
                      (the reference has no gradient), rank 0 / N=1 only, bounded sample.
 """
@@ -56,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise torch.distributed even for one rank (checks the RCCL path on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--no-ensemble", action="store_true", help="skip the C5 ensemble leg")
+    ap.add_argument("--ensemble-stars", type=int, default=32, help="stars of the ensemble leg (BASELINE C5: 32), spread over the ranks")
     ap.add_argument("--sharded-seconds", type=float, default=150.0, help="deadline of the sharded sampler leg (a hung exchange must not cost the line)")
     return ap.parse_args(argv)
 
@@ -220,11 +226,14 @@ def run_rank(args):
     # Instruction counts and HBM traffic need the PMC counters, which cannot be collected from inside this process:
     # they come from the committed rocprofv3 passes of this same command (tools/profile_round.sh ->
     # profiles/hbm_traffic.json).  Kernel time and core clock are this run's.
-    traffic, traffic_l, valu = None, None, None
+    traffic, traffic_l, valu, pmc_note = None, None, None, None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
             pm = json.load(open(tfile))
+            if pm.get("library") != tamcmc_amd.capi.version():
+                # counters of another build say nothing about this one's kernels: no instruction counts, no traffic
+                raise LookupError(f"profiles/hbm_traffic.json is of {pm.get('library')!r}, the loaded library is {tamcmc_amd.capi.version()!r}")
             scale = nchains / 64.0 * args.nx / 100000.0          # the PMC passes ran 64 chains x 1e5 bins
             traffic = pm.get("eval_grad_bytes_per_launch") * scale
             traffic_l = pm.get("eval_logL_bytes_per_launch") * scale
@@ -240,8 +249,9 @@ def run_rank(args):
                                          "source": "committed rocprofv3 --pmc SQ_INSTS_VALU pass of this command (profiles/hbm_traffic.json, build "
                                                    + str(pm.get("build", "?")) + ")"},
                     "model": "wave-level VALU instructions x 4 cycles / (1024 SIMDs x clock x kernel time): an upper bound, not every VALU instruction is a 4-cycle fp64 one"}
-        except Exception:
+        except Exception as e:           # noqa: BLE001
             traffic, traffic_l, valu = None, None, None
+            pmc_note = f"{type(e).__name__}: {e}"
     roofline = {
         "bound": "fp64-valu", "kernel": "tamcmc_eval_kernel<grad>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -249,7 +259,7 @@ def run_rank(args):
         "note": "achieved / peak / frac are the algorithmic bytes (16 B x Nx x chains) against the HBM peak, as the north-star "
                 "asks; the kernel is bound by fp64 VALU issue (SURVEY.md F6): x / y are shared by all chains through L2, so measured "
                 "HBM traffic (FETCH_SIZE doubled per the gfx950 calibration, + WRITE_SIZE) is ~4x below the algorithmic bytes",
-        "valu": valu,
+        "valu": valu, "pmc_note": pmc_note, "library": tamcmc_amd.capi.version(),
         "logL_only": {"achieved": round(bytes_per_launch / kl_avg_s / 1e9, 2),
                       "frac": round(bytes_per_launch / kl_avg_s / 1e9 / HBM_PEAK_GBS, 5),
                       "kernel_ms": round(kl_avg_s * 1e3, 4), "traffic": traffic_l},
@@ -275,6 +285,15 @@ def run_rank(args):
                                                  key + "_max_call_us": round(float(dts.max()) * 1e6, 1)})
         host_path["unit"] = "chain-steps/s through tamcmc_eval_batch (host pointers, PCIe copies + wait included)"
         acc.set_stream(stream.cuda_stream)
+
+    # ---- BASELINE config C5: the ensemble.  Every rank holds its share of the stars in one multi-spectrum context;
+    # nothing is exchanged in the timed region ("replicas only": independent stars).
+    ensemble = None
+    if not args.no_ensemble:
+        try:
+            ensemble = ensemble_leg(args, w, m_true, dist, rank, world, local, dev, comm_dev, stream)
+        except Exception as e:          # noqa: BLE001 -- report, keep the line
+            ensemble = {"error": f"{type(e).__name__}: {e}"}
 
     # the whole sampler loop (SURVEY.md 8f N1+N2: proposals, priors, accept/reject, adaptation and parallel tempering in
     # host C++; one likelihood batch per iteration): iterations/s of MALA::execute's loop body, all chains
@@ -321,7 +340,8 @@ def run_rank(args):
                        "prewarm_ms": PREWARM_MS},
             "logL_only": {"value": round(value_l, 1), "unit": "chain-steps/s (model+logL)",
                           "ms_per_step": round(dt_l / args.steps * 1e3, 4)},
-            "host_path": host_path, "sampler": sampler_rate, "sampler_sharded": None, "roofline": roofline, "cpu_baseline": cpu,
+            "host_path": host_path, "ensemble": ensemble, "sampler": sampler_rate, "sampler_sharded": None, "roofline": roofline,
+            "cpu_baseline": cpu,
         }
 
     # ---- sharded sampler: 64 N chains over the N ranks, PT every iteration, boundary pairs between neighbours.
@@ -365,14 +385,70 @@ def run_rank(args):
             el = time.perf_counter() - t0
             if el >= args.cpu_seconds or n_it >= 2000:
                 break
-        out["cpu_baseline"] = cpu = {"value": round(nchains * n_it / el, 2), "unit": "chain-steps/s", "cores": int(cores), "kind": "port",
+        out["cpu_baseline"] = cpu = {"value": round(nchains * n_it / el, 2), "unit": "chain-steps/s", "cores": int(cores),
+               "threads_busy": int(min(cores, nchains)), "kind": "port",
                "sample": f"{n_it} iterations x {nchains} chains x {args.nx} bins, logL only (the reference has no "
-                         f"gradient), OpenMP over chains, {el:.1f} s"}
+                         f"gradient), OpenMP over chains (one thread per chain at most: threads_busy), {el:.1f} s"}
 
     emit()
     acc.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ensemble_leg(args, w, m_true, dist, rank, world, local, dev, comm_dev, stream):
+    """BASELINE.json config C5: `--ensemble-stars` (32) independent synthetic stars x 16 tempered chains each, the stars
+    dealt to the ranks in contiguous blocks.  A rank's stars share one context (same grid and layout, one spectrum each:
+    tamcmc_ctx_set_spectra / _set_chain_spectrum), so its 16 * stars_per_rank chains are ONE batch per step; a chain's
+    result is bit for bit what a context of its own would return (tests/test_baseline_configs_gpu.py).  Timed like the
+    main leg: barrier + synchronize on both sides, exactly --steps steps, MAX over ranks; no communication inside."""
+    import numpy as np
+    import torch
+    import tamcmc_amd
+    from tamcmc_amd import shard, synth
+    stars, nch = int(args.ensemble_stars), 16
+    if stars % world != 0:
+        return {"skipped": f"{stars} stars do not divide over {world} ranks"}
+    ns = stars // world
+    mine = range(rank * ns, (rank + 1) * ns)
+    Y = np.stack([synth.make_spectrum(m_true, seed=1000 + k) for k in mine])
+    P = synth.chain_params(w, stars * nch, seed=11)[rank * ns * nch:(rank + 1) * ns * nch]
+    T = np.tile(synth.temperatures(nch), ns)
+    n = ns * nch
+    nvars = int(w["index_to_relax"].size)
+    with tamcmc_amd.Accel(2, w["plength"], w["x"], Y[0], device_id=local) as acc:
+        acc.set_vars(w["index_to_relax"])
+        acc.set_spectra(Y)
+        acc.set_chain_spectrum(np.repeat(np.arange(ns, dtype=np.int32), nch))
+        acc.set_stream(stream.cuda_stream)
+        dP = torch.from_numpy(np.ascontiguousarray(P)).to(dev)
+        dT = torch.from_numpy(np.ascontiguousarray(T)).to(dev)
+        dL = torch.empty(n, dtype=torch.float64, device=dev)
+        dG = torch.empty(n, nvars, dtype=torch.float64, device=dev)
+        dS = torch.empty(n, dtype=torch.int32, device=dev)
+
+        def step(grad):
+            acc.eval_batch_device(n, dP.data_ptr(), dT.data_ptr(), dL.data_ptr(), dG.data_ptr() if grad else 0, dS.data_ptr())
+
+        def sync():
+            torch.cuda.synchronize(dev)
+
+        out = {"stars_total": stars, "chains_per_star": nch, "stars_per_rank": ns, "chains_per_rank": n, "scaling": "strong",
+               "what": "32/N stars per rank in one multi-spectrum context, one batch per step, no communication in the timed region"}
+        steps = max(10, min(args.steps, 200))
+        for grad, key in ((True, "chain_steps_per_s"), (False, "logL_only_chain_steps_per_s")):
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < PREWARM_MS:
+                for _ in range(5):
+                    step(grad)
+                sync()
+            dt = shard.timed_loop(lambda: step(grad), steps, sync, dist=dist, device=comm_dev)
+            out[key] = round(stars * nch * steps / dt, 1)
+            out[("ms_per_step" if grad else "logL_only_ms_per_step")] = round(dt / steps * 1e3, 4)
+        assert int(dS.abs().sum().item()) == 0 and bool(torch.isfinite(dL).all()) and bool(torch.isfinite(dG).all())
+        out["steps"] = steps
+        acc.set_stream(0)
+    return out
 
 
 def sharded_sampler_leg(args, acc, w, dist, rank, world, nchains, dev, comm_dev):

@@ -130,6 +130,19 @@ int tamcmc_eval_batch_device(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams,
 int tamcmc_eval_batch_begin(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs);
 int tamcmc_eval_batch_end(tamcmc_ctx *ctx, int32_t Nchains, double *logL, int32_t *status);
 
+/* The same in two PARTS that may be in flight together (part = 0 or 1; part 1 runs on a stream of its own): chains
+ * [first, first + Nchains) of the context's numbering -- the ranges of two parts in flight must not overlap; with several
+ * spectra resident `first` also indexes the chain -> spectrum map.  For a sampler that splits its chains in two halves
+ * and handles one half's results on the host while the GPU evaluates the other (chains are independent inside an
+ * iteration, MALA.cpp:632-655).  params / Tcoefs point at the part's first row / entry.  A chain's result is bit for
+ * bit that of tamcmc_eval_batch (tests/test_parity_gpu.py).  tamcmc_ctx_reserve sizes the context's buffers for Nchains
+ * chains in total beforehand: they are never reallocated under a part in flight (a begin that would need to returns
+ * TAMCMC_E_INVALID).  No whole-batch call may be made while a part is in flight. */
+int tamcmc_ctx_reserve(tamcmc_ctx *ctx, int32_t Nchains);
+int tamcmc_eval_batch_begin_part(tamcmc_ctx *ctx, int32_t part, int32_t first, int32_t Nchains, int32_t Nparams,
+                                 const double *params, const double *Tcoefs);
+int tamcmc_eval_batch_end_part(tamcmc_ctx *ctx, int32_t part, double *logL, int32_t *status);
+
 /* Replaces: Model_def::call_model_explicit (model_def.cpp:199-208) as used by tools/getmodel.cpp:111.
  * One params row -> model spectrum (Nx doubles, host).  *status gets the TAMCMC_CHAIN_* code. */
 int tamcmc_model_explicit(tamcmc_ctx *ctx, int32_t Nparams, const double *params,

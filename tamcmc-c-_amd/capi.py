@@ -20,6 +20,7 @@ EXPORTS = [
     "tamcmc_ctx_create", "tamcmc_ctx_set_vars", "tamcmc_ctx_set_spectra", "tamcmc_ctx_set_chain_spectrum",
     "tamcmc_eval_batch", "tamcmc_eval_batch_device",
     "tamcmc_eval_batch_begin", "tamcmc_eval_batch_end",
+    "tamcmc_ctx_reserve", "tamcmc_eval_batch_begin_part", "tamcmc_eval_batch_end_part",
     "tamcmc_model_explicit", "tamcmc_ctx_set_stream", "tamcmc_ctx_synchronize", "tamcmc_ctx_profile",
     "tamcmc_ctx_kernel_time", "tamcmc_ctx_clock_probe_begin", "tamcmc_ctx_clock_probe_end", "tamcmc_ctx_geometry", "tamcmc_ctx_destroy", "tamcmc_device_count",
     "tamcmc_strerror", "tamcmc_last_hip_error", "tamcmc_version",
@@ -54,6 +55,9 @@ def load_library():
     lib.tamcmc_eval_batch.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, C.c_int32, ip, dp, ip]
     lib.tamcmc_eval_batch_device.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
     lib.tamcmc_model_explicit.argtypes = [vp, C.c_int32, dp, dp, ip]
+    lib.tamcmc_ctx_reserve.argtypes = [vp, C.c_int32]
+    lib.tamcmc_eval_batch_begin_part.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, dp]
+    lib.tamcmc_eval_batch_end_part.argtypes = [vp, C.c_int32, dp, ip]
     lib.tamcmc_ctx_set_stream.argtypes = [vp, vp]
     lib.tamcmc_ctx_synchronize.argtypes = [vp]
     lib.tamcmc_ctx_profile.argtypes = [vp, C.c_int]
@@ -177,6 +181,28 @@ class Accel:
         if rows is not None:
             out.append(models)
         return tuple(out)
+
+    def reserve(self, nchains):
+        self._check(self._lib.tamcmc_ctx_reserve(self._ctx, int(nchains)), "tamcmc_ctx_reserve")
+
+    def begin_part(self, part, first, params, Tcoefs):
+        """Likelihood evaluation of chains [first, first + len(params)) as part 0 / 1; both parts may be in flight together."""
+        params = _c64(params)
+        if params.ndim != 2 or params.shape[1] != self.Nparams:
+            raise ValueError(f"expected (n, {self.Nparams}) params, got {params.shape}")
+        T = _c64(Tcoefs, (params.shape[0],))
+        self._part_n = getattr(self, "_part_n", {})
+        self._part_n[int(part)] = params.shape[0]
+        self._check(self._lib.tamcmc_eval_batch_begin_part(self._ctx, int(part), int(first), params.shape[0], self.Nparams,
+                                                           _dptr(params), _dptr(T)), "tamcmc_eval_batch_begin_part")
+
+    def end_part(self, part):
+        n = self._part_n[int(part)]
+        logL = np.empty(n)
+        st = np.empty(n, dtype=np.int32)
+        self._check(self._lib.tamcmc_eval_batch_end_part(self._ctx, int(part), _dptr(logL), st.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "tamcmc_eval_batch_end_part")
+        return logL, st
 
     def eval_batch_device(self, nchains, d_params, d_T, d_logL, d_grad=0, d_status=0):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); enqueued on the ctx stream, no sync."""

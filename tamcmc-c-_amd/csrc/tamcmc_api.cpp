@@ -73,7 +73,14 @@ struct tamcmc_ctx {
     double *dv_in = nullptr, *dv_out = nullptr;   // device views of h_in / h_out / h_status (looked up once per allocation)
     int32_t *dv_status = nullptr;
     hipEvent_t ev_done = nullptr;  // completion of a host-pointer call, polled (see wait_done)
+    bool ev_recorded = false;      // wait_data: the event of the current call has been recorded (lazily)
     int in_flight = 0;             // chains of a tamcmc_eval_batch_begin not yet collected by _end
+    // tamcmc_eval_batch_begin_part / _end_part: two sub-batches of the context's chains in flight at once, part 1 on a
+    // stream of its own; a part's rows of every per-chain buffer start at its first chain
+    hipStream_t part_stream = nullptr;
+    int part_first[2] = {0, 0}, part_n[2] = {0, 0};
+    bool part_ev_recorded[2] = {false, false};
+    hipEvent_t part_ev[2] = {nullptr, nullptr};
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
@@ -191,6 +198,7 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     const int cap = Nchains > c->cap ? Nchains : c->cap;
     const bool g = grad || c->cap_grad;
     TM_HIP(hipStreamSynchronize(c->stream));
+    if (c->part_stream) TM_HIP(hipStreamSynchronize(c->part_stream));
     free_batch(c);
     const size_t n = (size_t)cap;
     const int nm = c->L.n_mult > 0 ? c->L.n_mult : 1;
@@ -322,6 +330,8 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
     (void)hipHostFree(c->h_probe);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->part_stream) { (void)hipStreamSynchronize(c->part_stream); (void)hipStreamDestroy(c->part_stream); }
+    for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -499,26 +509,42 @@ static int pick_tiles(const tamcmc_ctx *c, int /*Nchains*/, bool grad)
 }
 
 // Enqueue setup -> eval (-> backward) for device-resident inputs.
+// base / stream: the sub-batch starts at chain `base` of the context's per-chain buffers (0 for a whole batch) and runs
+// on `stream` (the context stream for a whole batch).
 static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const double *d_T, double *d_logL,
-                   double *d_grad, int32_t *d_status, const int32_t *d_rows, double *d_model)
+                   double *d_grad, int32_t *d_status, const int32_t *d_rows, double *d_model, int base = 0, hipStream_t stream = nullptr)
 {
     const bool grad = d_grad != nullptr;
+    if (stream == nullptr) stream = c->stream;
     // several spectra resident: every chain of the batch must have been told which one it is fitted to (a batch longer
     // than the map used to fall back to spectrum 0 for all chains -- silently the wrong data)
-    if (c->nspec > 1 && (c->d_spec == nullptr || Nchains > c->spec_n)) return TAMCMC_E_INVALID;
+    if (c->nspec > 1 && (c->d_spec == nullptr || base + Nchains > c->spec_n)) return TAMCMC_E_INVALID;
     const int units = c->units, cells = c->cells;
     const int tiles = pick_tiles(c, Nchains, grad);
     if (!grad) c->last_tiles = tiles;
+    const size_t b = (size_t)base, nmx = (size_t)(c->L.n_mult > 0 ? c->L.n_mult : 1);
+    TmMult *const p_mult = c->d_mult + b * nmx;
+    TmNoise *const p_noise = c->d_noise + b;
+    TmCellRec *const p_cell = c->d_cell + b * cells;
+    TmTileHdr *const p_thdr = c->d_thdr + b * tiles;
+    TmActive *const p_tidx = c->d_tidx + b * tiles * nmx;
+    double *const p_wt = c->d_wt + b * 2, *const p_part = c->d_part + b * tiles * 4;
+    int32_t *const p_order = c->d_order + b * tiles, *const p_ticket = c->d_ticket + b;
+    double *const p_gmult = grad ? c->d_gmult + b * tiles * nmx * TM_GSLOTS : nullptr;
+    double *const p_gnoise = grad ? c->d_gnoise + b * tiles * 2 * TM_NSLOTS : nullptr;
+    double *const p_hser = grad ? c->d_hser + b * cells * TM_MAXH * TM_HSER : nullptr;
+    void *const p_chain_rec = grad ? (void *)((char *)c->d_chain_rec + b * tm_sizeof_chain_rec()) : nullptr;
+    void *const p_aux = grad ? (void *)((char *)c->d_aux + b * nmx * tm_sizeof_aux()) : nullptr;
     TmEvalArgs a{};
     a.x2 = c->d_x2; a.y = c->d_y; a.lx = c->d_lx; a.isig2 = c->d_isig2;
-    a.spec = (c->nspec > 1) ? c->d_spec : nullptr;
-    a.mult = c->d_mult; a.noise = c->d_noise; a.cell = c->d_cell; a.thdr = c->d_thdr; a.tidx = c->d_tidx; a.wt = c->d_wt;
-    a.part = c->d_part; a.gmult = grad ? c->d_gmult : nullptr; a.gnoise = grad ? c->d_gnoise : nullptr;
+    a.spec = (c->nspec > 1) ? c->d_spec + b : nullptr;
+    a.mult = p_mult; a.noise = p_noise; a.cell = p_cell; a.thdr = p_thdr; a.tidx = p_tidx; a.wt = p_wt;
+    a.part = p_part; a.gmult = p_gmult; a.gnoise = p_gnoise;
     a.row_of_chain = d_rows; a.model_out = d_model;
-    a.ticket = grad ? nullptr : c->d_ticket; a.logL = d_logL; a.status = d_status;
+    a.ticket = grad ? nullptr : p_ticket; a.logL = d_logL; a.status = d_status;
     a.Nx = c->L.Nx; a.n_mult = c->L.n_mult; a.tiles = tiles; a.cells = cells; a.likelihood_case = c->L.likelihood_case;
     a.like_p = c->L.like_p;
-    a.order = c->d_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio;
+    a.order = p_order; a.order_mode = (tiles <= 65535) ? c->order_mode : 0; a.prio = c->prio;
     a.generic = (c->L.likelihood_case != 0 || c->L.family == TM_FAM_GAUSS || d_rows != nullptr) ? 1 : 0;
     if (tiles == 1 && a.order_mode == 2) a.order_mode = 1;     // nothing to rank
     a.tile_magic = ((1ULL << 40) + (unsigned long long)tiles - 1) / (unsigned long long)tiles;
@@ -526,9 +552,9 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     const bool fused = (tiles == 1) && c->fuse != 0 && units <= TM_TILE_MAXU;   // (TAMCMC_TILES=1 on a 9..16-unit grid: two launches)
     int rc = 0;
     if (!fused) {
-        rc = tm_launch_setup(c->L, Nchains, d_params, d_T, c->d_wt, c->d_lx, units, cells, tiles, c->equal_cost, grad ? c->cost_g : c->cost_l,
-                             c->d_mult, c->d_noise, c->d_cell, c->d_thdr, c->d_tidx, grad ? c->d_chain_rec : nullptr, grad ? c->d_aux : nullptr,
-                             grad ? c->d_hser : nullptr, a.order_mode == 2 ? c->d_order : nullptr, c->stream);
+        rc = tm_launch_setup(c->L, Nchains, d_params, d_T, p_wt, c->d_lx, units, cells, tiles, c->equal_cost, grad ? c->cost_g : c->cost_l,
+                             p_mult, p_noise, p_cell, p_thdr, p_tidx, p_chain_rec, p_aux,
+                             p_hser, a.order_mode == 2 ? p_order : nullptr, stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "setup launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }
     const bool timed = c->profile && (c->profile_count++ % c->profile_stride == 0);
@@ -538,32 +564,32 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
             TM_HIP(hipEventCreate(&e));
             c->ev.push_back(e);
         }
-        TM_HIP(hipEventRecord(c->ev[c->ev_used], c->stream));
+        TM_HIP(hipEventRecord(c->ev[c->ev_used], stream));
     }
     if (fused) {
         TmFusedArgs f{};
         f.params = d_params; f.Tcoefs = d_T;
-        f.chain_rec = grad ? c->d_chain_rec : nullptr; f.aux = grad ? c->d_aux : nullptr; f.hser = grad ? c->d_hser : nullptr;
+        f.chain_rec = p_chain_rec; f.aux = p_aux; f.hser = p_hser;
         f.p_doubles = (c->L.Nparams + 1) & ~1;
-        rc = tm_launch_fused(c->L, f, a, Nchains, grad, c->stream);
+        rc = tm_launch_fused(c->L, f, a, Nchains, grad, stream);
     } else {
-        rc = tm_launch_eval(a, Nchains, grad, c->stream);
+        rc = tm_launch_eval(a, Nchains, grad, stream);
     }
     if (rc != 0) {
         snprintf(g_hip_err, sizeof(g_hip_err), "eval launch -> %s", hipGetErrorString((hipError_t)rc));
-        (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);   // arrival counters back to zero
+        (void)hipMemsetAsync(p_ticket, 0, (size_t)Nchains * sizeof(int32_t), stream);   // arrival counters back to zero
         return TAMCMC_E_HIP;
     }
     if (timed) {
-        TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        TM_HIP(hipEventRecord(c->ev[c->ev_used + 1], stream));
         c->ev_used += 2;
     }
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, tm_setup_balances(units, tiles, c->equal_cost, (grad ? c->cost_g : c->cost_l).pad), d_params, c->d_wt, c->d_chain_rec, c->d_aux, c->d_noise, c->d_part,
-                                c->d_gmult, c->d_gnoise, c->d_cell, c->d_thdr, c->d_hser, c->Nvars, c->d_relax, d_grad, d_logL, d_status,
-                                c->stream);
+        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, tm_setup_balances(units, tiles, c->equal_cost, (grad ? c->cost_g : c->cost_l).pad), d_params, p_wt, p_chain_rec, p_aux, p_noise, p_part,
+                                p_gmult, p_gnoise, p_cell, p_thdr, p_hser, c->Nvars, c->d_relax, d_grad, d_logL, d_status,
+                                stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     }
     return TAMCMC_OK;
@@ -580,7 +606,7 @@ extern "C" int tamcmc_eval_batch_device(tamcmc_ctx *c, int32_t Nchains, int32_t 
                                         double *d_logL, double *d_grad, int32_t *d_status)
 {
     if (!c || Nchains < 1 || !d_params || !d_Tcoefs || !d_logL) return TAMCMC_E_INVALID;
-    if (Nparams != c->L.Nparams) return TAMCMC_E_INVALID;
+    if (Nparams != c->L.Nparams || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;
     if (d_grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, d_grad != nullptr);
@@ -617,16 +643,25 @@ static void mark_pending(tamcmc_ctx *c, int n, size_t nw)
     for (size_t m = 0; m < nw; m++) o[m] = TM_PENDING_BITS;
     for (int m = 0; m < n; m++) c->h_status[m] = -1;
 }
-static int wait_data(tamcmc_ctx *c, int n, size_t nw)
+// o / st: first logL (then gradient) slot and first status slot of the (sub-)batch; ev / recorded / stream: its completion
+// event, recorded lazily; ticket / nticket: its arrival counters (re-armed when a launch retired without finalizing).
+static int wait_slots(tamcmc_ctx *c, volatile const uint64_t *o, volatile const int32_t *st, int n, size_t nw,
+                      hipEvent_t *ev, bool *recorded, hipStream_t stream, int32_t *ticket, int nticket)
 {
-    volatile const uint64_t *o = reinterpret_cast<volatile const uint64_t *>(c->h_out);
-    volatile const int32_t *st = c->h_status;
     unsigned spins = 0;
     for (size_t m = 0; m < nw;) {
         if (o[m] != TM_PENDING_BITS && (m >= (size_t)n || st[m] != -1)) { m++; continue; }
         __builtin_ia32_pause();
         if ((++spins & 2047u) == 0) {
-            const hipError_t e = hipEventQuery(c->ev_done);
+            // The completion event is recorded only now, behind the kernels already in the stream (it completes once they
+            // have): a call that gets its results within the first ~2000 polls -- every healthy call -- never pays for an
+            // event on the launch path (~1.5 us of host time per call in a sampler loop).
+            if (!*recorded) {
+                if (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return TAMCMC_E_HIP;
+                if (hipEventRecord(*ev, stream) != hipSuccess) return TAMCMC_E_HIP;
+                *recorded = true;
+            }
+            const hipError_t e = hipEventQuery(*ev);
             if (e == hipSuccess) {
                 // The launch has retired: whatever the slots hold is final.  A logL / status slot that still holds its
                 // marker was never written -- a chain whose finalize did not run (e.g. an arrival counter left non-zero
@@ -635,19 +670,24 @@ static int wait_data(tamcmc_ctx *c, int n, size_t nw)
                 for (size_t k = 0; k < (size_t)n; k++)
                     if (o[k] == TM_PENDING_BITS || st[k] == -1) {
                         snprintf(g_hip_err, sizeof(g_hip_err), "chain %zu was not finalized by a retired launch", k);
-                        (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);
+                        (void)hipMemsetAsync(ticket, 0, (size_t)nticket * sizeof(int32_t), stream);
                         return TAMCMC_E_HIP;
                     }
                 return TAMCMC_OK;
             }
             if (e != hipErrorNotReady) {
                 snprintf(g_hip_err, sizeof(g_hip_err), "hipEventQuery -> %s", hipGetErrorString(e));
-                (void)hipMemsetAsync(c->d_ticket, 0, (size_t)c->cap * sizeof(int32_t), c->stream);
+                (void)hipMemsetAsync(ticket, 0, (size_t)nticket * sizeof(int32_t), stream);
                 return TAMCMC_E_HIP;
             }
         }
     }
     return TAMCMC_OK;
+}
+static int wait_data(tamcmc_ctx *c, int n, size_t nw)
+{
+    return wait_slots(c, reinterpret_cast<volatile const uint64_t *>(c->h_out), c->h_status, n, nw, &c->ev_done, &c->ev_recorded,
+                      c->stream, c->d_ticket, c->cap);
 }
 
 // pinned, device-mapped staging of the host-pointer entry points
@@ -672,7 +712,7 @@ static int ensure_staging(tamcmc_ctx *c, int Nchains)
 
 extern "C" int tamcmc_eval_batch_begin(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs)
 {
-    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight) return TAMCMC_E_INVALID;
+    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, false);
     if (rc != TAMCMC_OK) return rc;
@@ -687,8 +727,7 @@ extern "C" int tamcmc_eval_batch_begin(tamcmc_ctx *c, int32_t Nchains, int32_t N
     mark_pending(c, Nchains, (size_t)Nchains);
     rc = enqueue(c, Nchains, dv_in, dv_in + n * Nparams, dv_out, nullptr, dv_status, nullptr, nullptr);
     if (rc != TAMCMC_OK) return rc;
-    if (!c->ev_done) TM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-    TM_HIP(hipEventRecord(c->ev_done, c->stream));
+    c->ev_recorded = false;          // wait_data records the completion event only if the results are slow to arrive
     c->in_flight = Nchains;
     return TAMCMC_OK;
 }
@@ -700,6 +739,59 @@ extern "C" int tamcmc_eval_batch_end(tamcmc_ctx *c, int32_t Nchains, double *log
     { const int rc = wait_data(c, Nchains, (size_t)Nchains); if (rc != TAMCMC_OK) return rc; }
     std::memcpy(logL, c->h_out, (size_t)Nchains * sizeof(double));
     if (status) std::memcpy(status, c->h_status, (size_t)Nchains * sizeof(int32_t));
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_ctx_reserve(tamcmc_ctx *c, int32_t Nchains)
+{
+    if (!c || Nchains < 1 || c->in_flight || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;
+    TM_HIP(hipSetDevice(c->device));
+    if (c->part_stream) TM_HIP(hipStreamSynchronize(c->part_stream));
+    int rc = ensure_capacity(c, Nchains, false);
+    if (rc != TAMCMC_OK) return rc;
+    return ensure_staging(c, Nchains);
+}
+
+extern "C" int tamcmc_eval_batch_begin_part(tamcmc_ctx *c, int32_t part, int32_t first, int32_t Nchains, int32_t Nparams,
+                                            const double *params, const double *Tcoefs)
+{
+    if (!c || part < 0 || part > 1 || first < 0 || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams) return TAMCMC_E_INVALID;
+    if (c->in_flight || c->part_n[part]) return TAMCMC_E_INVALID;
+    const int other = 1 - part;
+    if (c->part_n[other] && first < c->part_first[other] + c->part_n[other] && c->part_first[other] < first + Nchains) return TAMCMC_E_INVALID;   // overlap
+    // buffers are never (re)allocated under a part in flight: tamcmc_ctx_reserve sizes them beforehand
+    if (first + Nchains > c->cap || first + Nchains > c->h_cap || c->h_nvars != c->Nvars) {
+        if (c->part_n[other]) return TAMCMC_E_INVALID;
+        const int rc = tamcmc_ctx_reserve(c, first + Nchains);
+        if (rc != TAMCMC_OK) return rc;
+    }
+    TM_HIP(hipSetDevice(c->device));
+    if (part == 1 && !c->part_stream) TM_HIP(hipStreamCreateWithFlags(&c->part_stream, hipStreamNonBlocking));
+    hipStream_t stream = (part == 0) ? c->stream : c->part_stream;
+    const size_t f = (size_t)first, n = (size_t)Nchains, np = (size_t)Nparams, hc = (size_t)c->h_cap;
+    std::memcpy(c->h_in + f * np, params, n * np * sizeof(double));
+    std::memcpy(c->h_in + hc * np + f, Tcoefs, n * sizeof(double));
+    uint64_t *o = reinterpret_cast<uint64_t *>(c->h_out) + f;
+    for (size_t m = 0; m < n; m++) { o[m] = TM_PENDING_BITS; c->h_status[f + m] = -1; }
+    const int rc = enqueue(c, Nchains, c->dv_in + f * np, c->dv_in + hc * np + f, c->dv_out + f, nullptr, c->dv_status + f, nullptr, nullptr,
+                           first, stream);
+    if (rc != TAMCMC_OK) return rc;
+    c->part_ev_recorded[part] = false;
+    c->part_first[part] = first; c->part_n[part] = Nchains;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_eval_batch_end_part(tamcmc_ctx *c, int32_t part, double *logL, int32_t *status)
+{
+    if (!c || part < 0 || part > 1 || !logL || !c->part_n[part]) return TAMCMC_E_INVALID;
+    const int n = c->part_n[part], first = c->part_first[part];
+    c->part_n[part] = 0;
+    hipStream_t stream = (part == 0) ? c->stream : c->part_stream;
+    const int rc = wait_slots(c, reinterpret_cast<volatile const uint64_t *>(c->h_out) + first, c->h_status + first, n, (size_t)n,
+                              &c->part_ev[part], &c->part_ev_recorded[part], stream, c->d_ticket + first, n);
+    if (rc != TAMCMC_OK) return rc;
+    std::memcpy(logL, c->h_out + first, (size_t)n * sizeof(double));
+    if (status) std::memcpy(status, c->h_status + first, (size_t)n * sizeof(int32_t));
     return TAMCMC_OK;
 }
 
@@ -715,12 +807,12 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     for (int r = 0; r < n_rows; r++)
         if (model_rows[r] < 0 || model_rows[r] >= Nchains) return TAMCMC_E_INVALID;
     if (grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }
+    if (c->in_flight || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;   // (buffers may move below)
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, grad != nullptr);
     if (rc != TAMCMC_OK) return rc;
 
     const size_t n = (size_t)Nchains;
-    if (c->in_flight) return TAMCMC_E_INVALID;
     rc = ensure_staging(c, Nchains);
     if (rc != TAMCMC_OK) return rc;
     std::memcpy(c->h_in, params, n * Nparams * sizeof(double));
@@ -761,8 +853,7 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
         }
     }
     if (watch) {
-        if (!c->ev_done) TM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-        TM_HIP(hipEventRecord(c->ev_done, c->stream));
+        c->ev_recorded = false;
         rc = wait_data(c, Nchains, nwatch);
     } else {
         rc = wait_done(c);
@@ -804,4 +895,7 @@ extern "C" const char *tamcmc_strerror(int code)
 }
 
 extern "C" const char *tamcmc_last_hip_error(void) { return g_hip_err; }
-extern "C" const char *tamcmc_version(void) { return "tamcmc_accel 0.1 (gfx950)"; }
+#ifndef TM_KERNEL_HASH
+#define TM_KERNEL_HASH "unknown"
+#endif
+extern "C" const char *tamcmc_version(void) { return "tamcmc_accel 0.3 (gfx950) kernels:" TM_KERNEL_HASH; }

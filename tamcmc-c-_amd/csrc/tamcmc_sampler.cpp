@@ -531,6 +531,12 @@ struct tamcmc_sampler {
     // which precede them in the stream) are consumed right after the evaluation of iteration i was launched.
     bool drawn_ahead = false;                    // plans / u_mh / z_all already hold the draws of the coming mh_step
     bool pt_cached = false;                      // parallel-tempering draws of the current iteration already consumed
+    // With the draws of iteration i+1 in hand, chain m's next proposal needs nothing but chain m's own state after its
+    // accept step: it is computed in the SAME pass over the chains (one fork of the thread pool per iteration instead
+    // of two, chain m's rows still in its core's cache).  A parallel-tempering swap, which comes in between
+    // (MALA.cpp:676), re-proposes the two chains it touched; setters of restored state drop the flag.
+    bool proposed_ahead = false;                 // v_prop / p_prop already hold the proposals of the coming mh_step
+    std::atomic<int64_t> bad_chol_ahead{0};
     int32_t pt_A = 0;
     double pt_u = 0.0;
     tamcmc_ctx *hip_ctx = nullptr;               // set by create_hip: the evaluation can be split in begin / end
@@ -758,6 +764,34 @@ static void draw_pt(tamcmc_sampler *s)
 
 extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s);
 
+// Proposal of local chain m from its current vars and the normals in z_all: v' = v + chol((Sigma + eps2 I) sigma) z
+// (MALA.cpp:335-353), the factor recomputed only when the proposal parameters changed.  Returns false when the matrix
+// was not positive definite.
+static bool propose_chain(tamcmc_sampler *s, int m)
+{
+    const int nv = s->Nvars, np = s->Nparams;
+    bool ok = true;
+    if (!s->chol_valid[m]) {
+        double *tmp = &s->chol_scratch[(size_t)m * (2 * (size_t)nv * nv + nv)];
+        const double *C = &s->covar[(size_t)m * nv * nv];
+        for (int a = 0; a < nv; a++)
+            for (int b = 0; b < nv; b++)
+                tmp[(size_t)a * nv + b] = (C[(size_t)a * nv + b] + (a == b ? s->cfg.epsilon2 : 0.0)) * s->sigma[m];   // :342
+        ok = cholesky(tmp, nv, &s->Lchol[(size_t)m * nv * nv], tmp + (size_t)nv * nv);
+        s->chol_valid[m] = 1;
+    }
+    const double *z = &s->z_all[(size_t)m * nv];
+    const double *Lc = &s->Lchol[(size_t)m * nv * nv];
+    for (int a = 0; a < nv; a++) {
+        double acc = 0.0;
+        for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * z[b];
+        s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + acc;             // :349
+    }
+    std::memcpy(&s->p_prop[(size_t)m * np], &s->params[(size_t)m * np], sizeof(double) * np);
+    for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
+    return ok;
+}
+
 extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
 {
     if (!s) return TAMCMC_E_INVALID;
@@ -774,26 +808,10 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     }
     s->drawn_ahead = false;
     std::atomic<int64_t> bad{0};
-    s->pool->run(n, [&](int m) {
-        if (!s->chol_valid[m]) {
-            double *tmp = &s->chol_scratch[(size_t)m * (2 * (size_t)nv * nv + nv)];
-            const double *C = &s->covar[(size_t)m * nv * nv];
-            for (int a = 0; a < nv; a++)
-                for (int b = 0; b < nv; b++)
-                    tmp[(size_t)a * nv + b] = (C[(size_t)a * nv + b] + (a == b ? s->cfg.epsilon2 : 0.0)) * s->sigma[m];   // :342
-            if (!cholesky(tmp, nv, &s->Lchol[(size_t)m * nv * nv], tmp + (size_t)nv * nv)) bad.fetch_add(1, std::memory_order_relaxed);
-            s->chol_valid[m] = 1;
-        }
-        const double *z = &s->z_all[(size_t)m * nv];
-        const double *Lc = &s->Lchol[(size_t)m * nv * nv];
-        for (int a = 0; a < nv; a++) {
-            double acc = 0.0;
-            for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * z[b];
-            s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + acc;             // :349
-        }
-        std::memcpy(&s->p_prop[(size_t)m * np], &s->params[(size_t)m * np], sizeof(double) * np);
-        for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
-    });
+    if (!s->proposed_ahead)
+        s->pool->run(n, [&](int m) { if (!propose_chain(s, m)) bad.fetch_add(1, std::memory_order_relaxed); });
+    s->proposed_ahead = false;
+    bad.fetch_add(s->bad_chol_ahead.exchange(0), std::memory_order_relaxed);
     s->bad_chol += bad.load();
     t1 = now(); s->t_phase[0] += t1 - t0; t0 = t1;
     // 2. the hot path: every local chain in one call.  While the GPU works, consume the stream one iteration ahead:
@@ -833,6 +851,7 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     int64_t period = 1;
     const bool learn = learning_now(s, i, &period);
     std::atomic<int> perr_any{0};
+    const bool ahead = s->drawn_ahead;      // the normals of the next iteration are in z_all: propose in the same pass
     auto accept = [&](int m) {
         const double lpr = s->lpr_prop[m];
         if (s->perr_prop[m]) perr_any.store(1, std::memory_order_relaxed);
@@ -854,10 +873,12 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         }
         s->Pmove[m] = r;
         if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
+        if (ahead && !propose_chain(s, m)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
     };
     // (the fixed chain -> thread map of the pool keeps a chain's rows in the cache of the core that proposed them:
     // even the short accept step without adaptation is cheaper forked than pulled over to the calling thread)
     s->pool->run(n, accept);
+    s->proposed_ahead = ahead;
     t1 = now(); s->t_phase[5] += t1 - t0; s->t_iters++;
     const int perr = perr_any.load();
     return perr ? TAMCMC_E_INVALID : TAMCMC_OK;
@@ -920,6 +941,11 @@ static void pt_apply(tamcmc_sampler *s, int A, double u, const double *recA, con
             s->logPost[b] = (double)(logL_A_TB + (ld)recB[1]);
             s->moved[b] = (uint8_t)recA[2]; s->Pmove[b] = recA[3];
         }
+    }
+    if (sw && s->proposed_ahead) {      // the proposals computed ahead started from the rows just replaced
+        const int a = A - off, b = B - off;
+        if (a >= 0 && a < s->nloc && !propose_chain(s, a)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
+        if (b >= 0 && b < s->nloc && !propose_chain(s, b)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
     }
     if (swapped) *swapped = sw ? 1 : 0;
     if (r_out) *r_out = r_T;
@@ -1138,6 +1164,7 @@ extern "C" int tamcmc_sampler_set(tamcmc_sampler *s, int32_t which, const double
 {
     if (!s || !in) return TAMCMC_E_INVALID;
     const size_t n = (size_t)s->nloc, nv = (size_t)s->Nvars;
+    s->proposed_ahead = false;      // proposals computed ahead used the state being replaced
     switch (which) {
     case 0:
         if ((size_t)count != n * nv) return TAMCMC_E_INVALID;

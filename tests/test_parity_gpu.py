@@ -472,3 +472,39 @@ def test_likelihood_and_gradient_paths_return_the_same_logL_bits(accel_mod, orc,
         L, st = acc.eval_batch(P, T)
         Lg, stg, g = acc.eval_batch(P, T, grad=True)
     assert np.all(st == 0) and np.array_equal(L, Lg)
+
+
+def test_two_parts_in_flight_equal_one_batch(accel_mod, orc):
+    """tamcmc_eval_batch_begin_part / _end_part: two halves of a batch in flight together (part 1 on its own stream, per-chain
+    buffers offset by the part's first chain), ended in either order, uneven halves, many rounds with changing parameters:
+    every chain bit for bit what the whole batch returns; misuse (overlapping ranges, a whole-batch call under a part in
+    flight, growing the buffers under a part in flight) is refused."""
+    w = synth.workload_c2(Nx=40000)
+    y = spectrum_for(orc, w)
+    n = 24
+    T = synth.temperatures(n)
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        acc.reserve(n)
+        for rnd in range(12):
+            P = synth.chain_params(w, n, seed=100 + rnd)
+            cut = (12, 5, 19, 1)[rnd % 4]
+            acc.begin_part(0, 0, P[:cut], T[:cut])
+            acc.begin_part(1, cut, P[cut:], T[cut:])
+            if rnd % 2:
+                L1, s1 = acc.end_part(1); L0, s0 = acc.end_part(0)
+            else:
+                L0, s0 = acc.end_part(0); L1, s1 = acc.end_part(1)
+            L, st = acc.eval_batch(P, T)
+            assert np.array_equal(np.concatenate([L0, L1]), L) and np.array_equal(np.concatenate([s0, s1]), st)
+        rL, rst = orc.generate_batch(2, w["plength"], w["x"], y, P, T)
+        check_logL(L, rL)
+        acc.begin_part(0, 0, P[:12], T[:12])
+        for bad in (lambda: acc.begin_part(1, 8, P[8:], T[8:]),            # overlaps part 0
+                    lambda: acc.eval_batch(P, T),                           # whole batch under a part in flight
+                    lambda: acc.begin_part(1, 12, np.tile(P, (3, 1)), np.tile(T, 3))):   # would grow the buffers
+            with pytest.raises(accel_mod.AccelError):
+                bad()
+        L0, _ = acc.end_part(0)
+        assert np.array_equal(L0, L[:12])
+        L2, _ = acc.eval_batch(P, T)                                        # the context is fine afterwards
+        assert np.array_equal(L2, L)

@@ -14,6 +14,14 @@ def rows(d):
         yield from csv.DictReader(open(f))
 
 
+def library_version():
+    """tamcmc_version() of the library the passes ran with (it carries a hash of the kernel sources): bench.py uses the
+    instruction counts only while this is the library it has loaded."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tamcmc_amd
+    return tamcmc_amd.capi.version()
+
+
 def main(out_dir):
     res = collections.defaultdict(dict)
     for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
@@ -62,7 +70,7 @@ def main(out_dir):
               "eval_grad_valu_insts_per_launch": res[kg]["SQ_INSTS_VALU"],
               "eval_logL_valu_insts_per_launch": res[kf]["SQ_INSTS_VALU"],
               "clock_GHz": {"grad": out["clock_GHz_long_kernels"].get(kg), "logL": out["clock_GHz_long_kernels"].get(kf)},
-              "note": out["note"]}
+              "library": library_version(), "note": out["note"]}
         json.dump(hb, open(os.path.join(out_dir, "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1, sort_keys=True)[:3000])
 
