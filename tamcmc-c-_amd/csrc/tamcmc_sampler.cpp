@@ -536,6 +536,13 @@ struct tamcmc_sampler {
     // of two, chain m's rows still in its core's cache).  A parallel-tempering swap, which comes in between
     // (MALA.cpp:676), re-proposes the two chains it touched; setters of restored state drop the flag.
     bool proposed_ahead = false;                 // v_prop / p_prop already hold the proposals of the coming mh_step
+    // Pipelined loop (tamcmc_sampler_run / _run_sharded with the HIP evaluator): the local chains in two halves, each its
+    // own sub-batch on its own stream (tamcmc_eval_batch_begin_part).  One half's accept step, next proposals and next
+    // launch happen on the host while the GPU evaluates the other half -- chains are independent inside an iteration
+    // (MALA.cpp:632-655) and no draw depends on an outcome, so every chain sees exactly the numbers of the plain loop.
+    int split = 0;                               // chains in the first half; 0: pipelining off
+    bool inflight = false;                       // both halves of iteration `iter` are launched (only inside a run call)
+    bool reserved = false;                       // the context's buffers are sized for nloc chains
     std::atomic<int64_t> bad_chol_ahead{0};
     int32_t pt_A = 0;
     double pt_u = 0.0;
@@ -608,6 +615,14 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         if (nt < 1) nt = 1;
         s->pool.reset(new ChainPool(nt));
     { const char *e = getenv("TAMCMC_SAMPLER_TIMING"); s->timing = e && e[0] == '1'; }
+    {   // Two halves in flight (pipelined_iteration): OFF unless TAMCMC_SAMPLER_PIPELINE=1.  Measured at 64 chains x 1e5 bins
+        // (profiles/README.md, round 3): the GPU disappears behind the host (wait 1 us per iteration) but the host's own
+        // serial work grows -- four launches instead of two (17 us), two pool forks for the accept step (24 us), and the
+        // priors and the draws of the next iteration (40 us) no longer have a GPU evaluation to hide under: 84 us per
+        // iteration against 65 us with one batch.  It pays only once the draws run on a thread of their own.
+        const char *e = getenv("TAMCMC_SAMPLER_PIPELINE");
+        s->split = (n >= 8 && e && e[0] == '1') ? n / 2 : 0;
+    }
     }
     s->rng.g.seed(cfg->seed);
     *out = s;
@@ -792,6 +807,166 @@ static bool propose_chain(tamcmc_sampler *s, int m)
     return ok;
 }
 
+// Accept / reject and adaptation of local chain m (MALA.cpp:475-534, :641-652); with `ahead` the chain's next proposal
+// follows at once (the normals of the next iteration are in z_all).
+static inline void accept_chain(tamcmc_sampler *s, int m, int64_t i, double gamma, bool learn, int64_t period, bool ahead,
+                                std::atomic<int> &perr_any)
+{
+    const int nv = s->Nvars, np = s->Nparams;
+    const double lpr = s->lpr_prop[m];
+    if (s->perr_prop[m]) perr_any.store(1, std::memory_order_relaxed);
+    const double lpo = s->L_prop[m] + lpr;
+    double r;
+    if (!std::isnan(s->L_prop[m])) {
+        if (lpo == -std::numeric_limits<double>::infinity()) r = 0.;
+        else r = min1(std::exp(lpo - s->logPost[m]));
+    } else {
+        r = 0.;
+    }
+    if (s->u_now[m] <= r) {
+        std::memcpy(&s->params[(size_t)m * np], &s->p_prop[(size_t)m * np], sizeof(double) * np);
+        std::memcpy(&s->vars[(size_t)m * nv], &s->v_prop[(size_t)m * nv], sizeof(double) * nv);
+        s->logL[m] = s->L_prop[m]; s->logPrior[m] = lpr; s->logPost[m] = lpo;
+        s->moved[m] = 1;
+    } else {
+        s->moved[m] = 0;
+    }
+    s->Pmove[m] = r;
+    if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
+    if (ahead && !propose_chain(s, m)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
+}
+
+static void drain_parts(tamcmc_sampler *s)
+{
+    if (!s->inflight) return;
+    std::vector<double> l((size_t)s->nloc);
+    (void)tamcmc_eval_batch_end_part(s->hip_ctx, 0, l.data(), nullptr);
+    (void)tamcmc_eval_batch_end_part(s->hip_ctx, 1, l.data(), nullptr);
+    s->inflight = false;
+}
+
+// One iteration of the pipelined loop.  pt_step() is the caller's parallel-tempering step (draw, local swap or boundary
+// exchange, bookkeeping); it is called exactly once, when the accept step of every local chain of the drawn pair is done
+// and before those chains are launched again.  moved_row (may be NULL) receives the acceptance flags as they are BEFORE
+// the swap (what the plain loop records).  launch_next: leave iteration iter + 1 in flight on return.
+template <class PT>
+static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *moved_row, PT &&pt_step)
+{
+    const int n = s->nloc, nv = s->Nvars, np = s->Nparams, off = s->cfg.chain_offset, h = s->split;
+    const int64_t i = s->iter;
+    const double gamma = s->cfg.c0 / (1. + (double)i);             // MALA.cpp:630
+    auto now = [&]() { return s->timing ? wall_now() : 0.0; };
+    double t0 = now(), t1;
+    const int m0[2] = {0, h}, cnt[2] = {h, n - h};
+    auto launch = [&](int hh) {
+        return tamcmc_eval_batch_begin_part(s->hip_ctx, hh, m0[hh], cnt[hh], np, &s->p_prop[(size_t)m0[hh] * np], &s->T[off + m0[hh]]);
+    };
+    int rc = TAMCMC_OK;
+    std::atomic<int64_t> bad{0};
+    if (!s->inflight) {
+        // pipeline start: this iteration's draws and proposals (unless made ahead), both halves launched
+        if (!s->reserved) { rc = tamcmc_ctx_reserve(s->hip_ctx, n); if (rc != TAMCMC_OK) return rc; s->reserved = true; }
+        if (!s->drawn_ahead) {
+            draw_mh(s);
+            s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+        }
+        s->drawn_ahead = false;
+        if (!s->proposed_ahead)
+            s->pool->run(n, [&](int m) { if (!propose_chain(s, m)) bad.fetch_add(1, std::memory_order_relaxed); });
+        s->proposed_ahead = false;
+        t1 = now(); s->t_phase[0] += t1 - t0; t0 = t1;
+        rc = launch(0);
+        if (rc == TAMCMC_OK) { rc = launch(1); if (rc != TAMCMC_OK) { s->inflight = true; drain_parts(s); } }
+        if (rc != TAMCMC_OK) return rc;
+        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+    }
+    s->inflight = true;
+    bad.fetch_add(s->bad_chol_ahead.exchange(0), std::memory_order_relaxed);
+    s->bad_chol += bad.load();
+    // while the GPU works: priors of the proposals in flight, then the stream one iteration ahead (the parallel-tempering
+    // draws of THIS iteration come first in it, MALA.cpp:384,390)
+    s->u_now = s->u_mh;
+    s->pool->run(n, [&](int m) {
+        int perr = 0;
+        s->lpr_prop[m] = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+        s->perr_prop[m] = perr;
+    });
+    t1 = now(); s->t_phase[2] += t1 - t0; t0 = t1;
+    const bool due = tamcmc_sampler_pt_due(s) != 0;
+    if (due && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
+    draw_mh(s);
+    s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+    s->drawn_ahead = true;
+    t1 = now(); s->t_phase[3] += t1 - t0; t0 = t1;
+
+    // the half holding the local chain(s) of the drawn pair goes first; a pair with one chain in each half needs both
+    int first = 0;
+    bool together = false, local = false;
+    if (due) {
+        const int a = s->pt_A - off, b = a + 1;
+        const bool inA = a >= 0 && a < n, inB = b >= 0 && b < n;
+        local = inA || inB;
+        if (inA && inB && (a < h) != (b < h)) together = true;
+        else if (local) first = ((inA ? a : b) < h) ? 0 : 1;
+    }
+    int64_t period = 1;
+    const bool learn = learning_now(s, i, &period);
+    std::atomic<int> perr_any{0};
+    auto finish_half = [&](int hh) {
+        int r = tamcmc_eval_batch_end_part(s->hip_ctx, hh, &s->L_prop[(size_t)m0[hh]], &s->status[(size_t)m0[hh]]);
+        t1 = now(); s->t_phase[4] += t1 - t0; t0 = t1;
+        if (r != TAMCMC_OK) return r;
+        s->pool->run(cnt[hh], [&](int k) { accept_chain(s, m0[hh] + k, i, gamma, learn, period, true, perr_any); });
+        if (moved_row) std::memcpy(moved_row + m0[hh], &s->moved[(size_t)m0[hh]], (size_t)cnt[hh]);
+        t1 = now(); s->t_phase[5] += t1 - t0; t0 = t1;
+        return (int)TAMCMC_OK;
+    };
+    auto fail = [&](int code, int pending_half) {      // leave nothing in flight behind an error
+        if (pending_half >= 0) { std::vector<double> l((size_t)n); (void)tamcmc_eval_batch_end_part(s->hip_ctx, pending_half, l.data(), nullptr); }
+        s->inflight = false; s->proposed_ahead = false;
+        return code;
+    };
+    if (together || !launch_next) {
+        // (also the last iteration of a call: nothing is launched ahead, so nothing is gained by splitting the host work)
+        rc = finish_half(0);
+        if (rc != TAMCMC_OK) return fail(rc, 1);
+        rc = finish_half(1);
+        if (rc != TAMCMC_OK) return fail(rc, -1);
+        s->inflight = false;
+        s->proposed_ahead = true;
+        rc = pt_step();
+        if (rc != TAMCMC_OK) return fail(rc, -1);
+        if (launch_next) {
+            rc = launch(0);
+            if (rc == TAMCMC_OK) { rc = launch(1); if (rc != TAMCMC_OK) return fail(rc, 0); }
+            else return fail(rc, -1);
+            s->inflight = true; s->proposed_ahead = false;
+            t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+        }
+    } else {
+        const int second = 1 - first;
+        rc = finish_half(first);
+        if (rc != TAMCMC_OK) return fail(rc, second);
+        s->proposed_ahead = true;                       // (for the pair's chains: a swap re-proposes them, pt_apply)
+        if (local) { rc = pt_step(); if (rc != TAMCMC_OK) return fail(rc, second); }
+        rc = launch(first);
+        if (rc != TAMCMC_OK) return fail(rc, second);
+        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+        rc = finish_half(second);
+        if (rc != TAMCMC_OK) return fail(rc, first);
+        if (!local) { rc = pt_step(); if (rc != TAMCMC_OK) return fail(rc, first); }
+        rc = launch(second);
+        if (rc != TAMCMC_OK) return fail(rc, first);
+        s->inflight = true; s->proposed_ahead = false;
+        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+    }
+    s->t_iters++;
+    if (perr_any.load()) { if (s->inflight) drain_parts(s); s->proposed_ahead = false; return TAMCMC_E_INVALID; }
+    return TAMCMC_OK;
+}
+
+static bool pipeline_on(const tamcmc_sampler *s) { return s->hip_ctx != nullptr && s->split > 0; }
+
 extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
 {
     if (!s) return TAMCMC_E_INVALID;
@@ -852,29 +1027,7 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     const bool learn = learning_now(s, i, &period);
     std::atomic<int> perr_any{0};
     const bool ahead = s->drawn_ahead;      // the normals of the next iteration are in z_all: propose in the same pass
-    auto accept = [&](int m) {
-        const double lpr = s->lpr_prop[m];
-        if (s->perr_prop[m]) perr_any.store(1, std::memory_order_relaxed);
-        const double lpo = s->L_prop[m] + lpr;
-        double r;
-        if (!std::isnan(s->L_prop[m])) {
-            if (lpo == -std::numeric_limits<double>::infinity()) r = 0.;
-            else r = min1(std::exp(lpo - s->logPost[m]));
-        } else {
-            r = 0.;
-        }
-        if (s->u_now[m] <= r) {
-            std::memcpy(&s->params[(size_t)m * np], &s->p_prop[(size_t)m * np], sizeof(double) * np);
-            std::memcpy(&s->vars[(size_t)m * nv], &s->v_prop[(size_t)m * nv], sizeof(double) * nv);
-            s->logL[m] = s->L_prop[m]; s->logPrior[m] = lpr; s->logPost[m] = lpo;
-            s->moved[m] = 1;
-        } else {
-            s->moved[m] = 0;
-        }
-        s->Pmove[m] = r;
-        if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
-        if (ahead && !propose_chain(s, m)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
-    };
+    auto accept = [&](int m) { accept_chain(s, m, i, gamma, learn, period, ahead, perr_any); };
     // (the fixed chain -> thread map of the pool keeps a chain's rows in the cache of the core that proposed them:
     // even the short accept step without adaptation is cheaper forked than pulled over to the calling thread)
     s->pool->run(n, accept);
@@ -980,16 +1133,25 @@ extern "C" int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *mo
 {
     if (!s || s->nloc != s->cfg.Nchains) return TAMCMC_E_INVALID;   // single process only
     for (int64_t k = 0; k < n_iter; k++) {
-        int rc = tamcmc_sampler_mh_step(s);
-        if (rc != TAMCMC_OK) return rc;
-        if (moved_hist) std::memcpy(moved_hist + (size_t)k * s->nloc, s->moved.data(), s->nloc);
         int32_t sh = -1;
-        if (tamcmc_sampler_pt_due(s)) {
+        auto pt_step = [&]() {
+            if (!tamcmc_sampler_pt_due(s)) return (int)TAMCMC_OK;
             int32_t A, swapped; double u, r;
             tamcmc_sampler_pt_draw(s, &A, &u);
-            rc = tamcmc_sampler_pt_local(s, A, u, &swapped, &r);
+            const int rc2 = tamcmc_sampler_pt_local(s, A, u, &swapped, &r);
+            if (rc2 == TAMCMC_OK) sh = 2 * A + swapped;
+            return rc2;
+        };
+        int rc;
+        if (pipeline_on(s)) {
+            rc = pipelined_iteration(s, k + 1 < n_iter, moved_hist ? moved_hist + (size_t)k * s->nloc : nullptr, pt_step);
             if (rc != TAMCMC_OK) return rc;
-            sh = 2 * A + swapped;
+        } else {
+            rc = tamcmc_sampler_mh_step(s);
+            if (rc != TAMCMC_OK) return rc;
+            if (moved_hist) std::memcpy(moved_hist + (size_t)k * s->nloc, s->moved.data(), s->nloc);
+            rc = pt_step();
+            if (rc != TAMCMC_OK) return rc;
         }
         if (swap_hist) swap_hist[k] = sh;
         s->iter++;
@@ -1083,32 +1245,44 @@ extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tam
     struct Done { int64_t *p; const int64_t &k; ~Done() { if (p) *p = k; } } report{done, k};   // also on the error returns
     for (; k < n_iter; k++) {
         if (block && block->n >= block->cap) break;                    // the caller gathers the block, resets it, calls again
-        int rc = tamcmc_sampler_mh_step(s);
-        if (rc != TAMCMC_OK) return rc;
-        if (moved_hist) std::memcpy(moved_hist + (size_t)k * nloc, s->moved.data(), (size_t)nloc);
         double att = 0.0, Ad = -1.0, r = std::numeric_limits<double>::quiet_NaN(), swd = -1.0;
         int32_t sh = -1;
-        if (tamcmc_sampler_pt_due(s)) {
+        auto pt_step = [&]() {
+            if (!tamcmc_sampler_pt_due(s)) return (int)TAMCMC_OK;
             int32_t A, swapped = 0; double u, rT = 0.0;
             tamcmc_sampler_pt_draw(s, &A, &u);                        // same values in every process (replicated stream)
             att = 1.0; Ad = (double)A; sh = -2;                       // -2: attempted, this process owns neither end
             const bool ownA = (A >= off && A < off + nloc), ownB = (A + 1 >= off && A + 1 < off + nloc);
+            int rc2 = TAMCMC_OK;
             if (ownA && ownB) {
-                rc = tamcmc_sampler_pt_local(s, A, u, &swapped, &rT);
-                if (rc != TAMCMC_OK) return rc;
+                rc2 = tamcmc_sampler_pt_local(s, A, u, &swapped, &rT);
+                if (rc2 != TAMCMC_OK) return rc2;
                 r = rT; swd = (double)swapped; sh = 2 * A + swapped;
             } else if (ownA || ownB) {
-                if (!exchange) return TAMCMC_E_INVALID;
+                if (!exchange) return (int)TAMCMC_E_INVALID;
                 const int mine = ownA ? A : A + 1, peer = ownA ? A + 1 : A;
                 tamcmc_sampler_pt_export(s, mine, send.data());
                 const double t0 = s->timing ? wall_now() : 0.0;
-                rc = exchange(user, mine, peer, send.data(), recv.data(), nrec);
+                rc2 = exchange(user, mine, peer, send.data(), recv.data(), nrec);
                 if (s->timing) s->t_phase[7] += wall_now() - t0;
-                if (rc != 0) return TAMCMC_E_INVALID;
-                rc = tamcmc_sampler_pt_import(s, A, u, recv.data(), &swapped, &rT);
-                if (rc != TAMCMC_OK) return rc;
+                if (rc2 != 0) return (int)TAMCMC_E_INVALID;
+                rc2 = tamcmc_sampler_pt_import(s, A, u, recv.data(), &swapped, &rT);
+                if (rc2 != TAMCMC_OK) return rc2;
                 r = rT; swd = (double)swapped; sh = 2 * A + swapped;
             }
+            return (int)TAMCMC_OK;
+        };
+        int rc;
+        if (pipeline_on(s)) {
+            const bool more = (k + 1 < n_iter) && !(block && block->n + 1 >= block->cap);
+            rc = pipelined_iteration(s, more, moved_hist ? moved_hist + (size_t)k * nloc : nullptr, pt_step);
+            if (rc != TAMCMC_OK) return rc;
+        } else {
+            rc = tamcmc_sampler_mh_step(s);
+            if (rc != TAMCMC_OK) return rc;
+            if (moved_hist) std::memcpy(moved_hist + (size_t)k * nloc, s->moved.data(), (size_t)nloc);
+            rc = pt_step();
+            if (rc != TAMCMC_OK) return rc;
         }
         if (swap_hist) swap_hist[k] = sh;
         if (block) shard_block_record(block, s, att, Ad, r, swd);

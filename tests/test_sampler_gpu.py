@@ -12,7 +12,12 @@ from tamcmc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_hip_and_oracle_drive_identical_chains(accel_mod, orc):
+@pytest.mark.parametrize("pipeline", ["0", "1"], ids=["one-batch", "two-halves-in-flight"])
+def test_hip_and_oracle_drive_identical_chains(accel_mod, orc, monkeypatch, pipeline):
+    """pipeline = 1: the opt-in loop that keeps the chains' two halves in flight as separate sub-batches and handles one
+    half on the host while the GPU evaluates the other (tamcmc_sampler.cpp: pipelined_iteration) -- same draws, same
+    decisions as the one-batch loop and as the oracle-driven sampler."""
+    monkeypatch.setenv("TAMCMC_SAMPLER_PIPELINE", pipeline)
     nch, nit = 8, 400
     w, sw, pp, b = tps.ms_global_prior_setup()
     w = dict(w); w["x"] = synth.grid(6000, 2300.0, 840.0 / 6000)
