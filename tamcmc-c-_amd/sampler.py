@@ -322,19 +322,47 @@ class ShardBlock:
 
 
 def neighbour_exchange(dist, chains_per_rank, device=None):
-    """The boundary-pair exchange of a sharded run: one record each way between the two owners (torch.distributed
-    send/recv: RCCL over xGMI on GPUs -- tensors on `device` -- or gloo on the CPU)."""
+    """The boundary-pair exchange of a sharded run (MALA.cpp:381-445 for a pair whose chains live on two ranks): one
+    record each way between the two owners, torch.distributed send/recv -- RCCL over the neighbours' xGMI link with the
+    tensors on `device`, or gloo on the CPU.
+
+    Buffers: one send / recv pair per neighbour, allocated at the first exchange with that neighbour and reused (on a GPU:
+    a pinned host pair and a device pair; the record travels numpy -> pinned -> device -> peer and back the same way,
+    with no allocation and no pageable copy per call).
+
+    Progress: only the two owners of the drawn pair ever enter this function; every other rank goes on with its next
+    iteration.  Send and receive are posted together (batch_isend_irecv = one ncclGroup), so neither owner waits for
+    the other's receive to be posted.  Each rank walks the iterations in order and at most one pair is drawn per
+    iteration, so the exchanges of two neighbours match in iteration order on both sides, and a rank that waits does so
+    on a neighbour that is at an EARLIER OR EQUAL iteration and has nothing later to wait for: the waits cannot form a
+    cycle (tests/test_exchange_progress_gloo.py: four ranks, one of them slow)."""
     import torch
+    bufs = {}
+
+    def buffers(peer, n):
+        b = bufs.get(peer)
+        if b is None or b[0].numel() != n:
+            hs, hr = torch.empty(n, dtype=torch.float64), torch.empty(n, dtype=torch.float64)
+            if device is not None:
+                hs, hr = hs.pin_memory(), hr.pin_memory()
+                ds, dr = torch.empty(n, dtype=torch.float64, device=device), torch.empty(n, dtype=torch.float64, device=device)
+            else:
+                ds, dr = hs, hr
+            b = bufs[peer] = (hs, hr, ds, dr, hs.numpy(), hr.numpy())
+        return b
 
     def exchange(my_chain, peer_chain, send):
         peer = peer_chain // chains_per_rank
-        t_send = torch.from_numpy(np.ascontiguousarray(send))
+        hs, hr, ds, dr, hs_np, hr_np = buffers(peer, int(send.size))
+        hs_np[:] = send
         if device is not None:
-            t_send = t_send.to(device)
-        t_recv = torch.empty_like(t_send)
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, t_send, peer), dist.P2POp(dist.irecv, t_recv, peer)]):
+            ds.copy_(hs, non_blocking=True)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, ds, peer), dist.P2POp(dist.irecv, dr, peer)]):
             req.wait()
-        return t_recv.cpu().numpy()
+        if device is not None:
+            hr.copy_(dr)                      # device -> pinned host; returns when the record is there
+        return hr_np
+    exchange.buffers = bufs                   # (tests look at the reuse)
     return exchange
 
 

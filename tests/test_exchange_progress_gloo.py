@@ -1,0 +1,99 @@
+"""The boundary-pair exchange of a sharded run must never hold back a rank that does not own an end of the drawn pair,
+and must not deadlock when the ranks run at different speeds (before it first meets RCCL on hardware).
+Four gloo ranks x 8 chains of one temperature ladder, parallel tempering every iteration, the loop in the library
+(tamcmc_sampler_run_sharded); rank 1's evaluator is artificially slow.  Checked:
+  * the run finishes and is bit for bit the single-process run (so every exchange matched its partner);
+  * a rank enters the exchange exactly as often as a pair with one end in its block was drawn (non-owners: never);
+  * ranks run ahead: until its FIRST exchange a rank proceeds at its own speed -- rank 3 (whose only neighbour is rank 2)
+    reaches that iteration in less than half the time the slow rank 1 needs for it;
+  * the per-neighbour send / recv buffers are allocated once and reused."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORLD, PER, NIT, SLOW_RANK, SLOW_S = 4, 8, 90, 1, 0.004
+
+
+def _sampler(offset, nloc, NCH, stamps=None, delay=0.0):
+    import test_priors_sampler as tps
+    from oracle import pyoracle as orc
+    from tamcmc_amd import sampler as S
+    from tamcmc_amd import synth
+    w, sw, pp, b = tps.ms_global_prior_setup()
+    w = dict(w); w["x"] = synth.grid(600, 2300.0, 840.0 / 600)
+    m, _ = orc.model(3, w["params_true"], w["plength"], w["x"])
+    y = synth.make_spectrum(m, seed=5)
+    base = tps.oracle_evaluator(orc, 3, w, y)
+
+    def evaluator(params, T):
+        if stamps is not None:
+            stamps.append(time.perf_counter())      # one call per iteration: the time iteration len(stamps) - 1 started
+        if delay:
+            time.sleep(delay)
+        return base(params, T)
+    cfg = S.default_cfg(NCH, chain_offset=offset, Nchains_local=nloc, seed=4321, Nt_learn=(10, 40, 100000),
+                        periods_learn=(1, 1), prior_fct_switch=2, dN_mixing=1)
+    smp = S.Sampler(cfg, evaluator, w["plength"], w["params_true"], w["relax"], w["err"], sw, pp, [1.0, 5.0, 0.5, 0.0])
+    smp.init()
+    return smp
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tamcmc_amd import sampler as S
+    NCH = world * PER
+    stamps, calls = [], []
+    smp = _sampler(rank * PER, PER, NCH, stamps, SLOW_S if rank == SLOW_RANK else 0.0)
+    inner = S.neighbour_exchange(dist, PER)
+
+    def exchange(mine, peer, send):
+        t0 = time.perf_counter()
+        out = inner(mine, peer, send)
+        calls.append((len(stamps) - 2, mine, peer, t0, time.perf_counter(), len(inner.buffers)))   # (stamps[0] is init's evaluation)
+        return out
+    dist.barrier()
+    t_start = time.perf_counter()
+    _, _, swaps = smp.run_sharded(NIT, exchange, history=True)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), vars=smp.get("vars"), logL=smp.get("logL"), swaps=swaps,
+             stamps=np.array(stamps[1:]) - t_start, calls=np.array(calls, dtype=np.float64).reshape(-1, 6))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_one_slow_no_rank_waits_without_owning_the_pair(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    NCH = WORLD * PER
+    ref = _sampler(0, NCH, NCH)
+    _, ref_swaps = ref.run(NIT)
+    R = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(WORLD)]
+    assert np.array_equal(np.concatenate([r["vars"] for r in R]), ref.get("vars"))          # bit for bit the single-process run
+    assert np.array_equal(np.concatenate([r["logL"] for r in R]), ref.get("logL"))
+    drawn = ref_swaps[ref_swaps >= 0] // 2                                                   # A of every attempt
+    for rank, r in enumerate(R):
+        lo, hi = rank * PER, (rank + 1) * PER
+        mine = [(it, int(a)) for it, a in enumerate(ref_swaps // 2) if ref_swaps[it] >= 0 and ((a == lo - 1) or (a == hi - 1 and hi < NCH))]
+        calls = r["calls"]
+        assert calls.shape[0] == len(mine), (rank, calls.shape[0], len(mine))               # owners only, once per owned boundary pair
+        assert [int(c[0]) for c in calls] == [it for it, _ in mine]
+        if calls.shape[0]:
+            assert np.all(calls[:, 5] <= 2) and calls[-1, 5] == len({int(c[2]) // PER for c in calls})   # one buffer set per neighbour, reused
+    assert (drawn % PER == PER - 1).sum() >= 3                                               # boundary pairs did come up
+    # running ahead: rank 3 depends on nobody until its first exchange
+    t1, t3 = R[SLOW_RANK]["stamps"], R[3]["stamps"]
+    first3 = int(R[3]["calls"][0, 0]) if R[3]["calls"].shape[0] else NIT - 1
+    assert first3 >= 4, "seed: rank 3's first boundary pair comes too early to measure anything"
+    assert t3[first3] < 0.5 * t1[first3], (first3, t3[first3], t1[first3])
+    # and nobody is faster than the slow rank by the end by construction of the coupling only where pairs were owned:
+    assert t1[-1] >= NIT * SLOW_S * 0.9
