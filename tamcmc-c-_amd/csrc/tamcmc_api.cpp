@@ -289,6 +289,28 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
             env_int("TAMCMC_TILES", tmin_l, 1 << 20, &c->tiles_l);
             env_int("TAMCMC_TILES_GRAD", tmin_g, 1 << 20, &c->tiles_g);
         }
+        // Tail shaping of the gradient launch (long grids, equal-length tiles): the first tiles keep TM_TILE_MAXU units, the
+        // rest -- cheaper, hence launched last under the costliest-first order -- get su2 units, so that the workgroups
+        // that end the launch are short (the launch is 1.56 rounds of resident workgroups at C2, and a round's last
+        // workgroups run on a nearly empty chip).  The long tiles cover `frac` percent of the units: 85 %, 4 units by
+        // default -- at 1e5 bins 21 tiles of 8 units + 7 of 4 (measured, profiles/README.md: C2 80.2 -> 78.1 us, C4 258 ->
+        // 251 us, 16 / 32 chains -1.1 us, 256 chains +1 %).  TAMCMC_TAIL="frac,su2" sets it, TAMCMC_TAIL=0 switches it off.
+        // A function of the grid only, like the tile count: a chain's result does not depend on the batch.
+        c->cost_g.t1 = 0;
+        {
+            const char *e = getenv("TAMCMC_TAIL");
+            int frac = 85, su2 = 4;
+            if (e && sscanf(e, "%d,%d", &frac, &su2) != 2) frac = 0;
+            if (frac >= 1 && frac <= 99 && su2 >= 1 && su2 <= TM_TILE_MAXU &&
+                c->units >= 70 && !c->equal_cost && !getenv("TAMCMC_TILES_GRAD")) {
+                const int t1 = (int)(((long long)c->units * frac / 100 + TM_TILE_MAXU / 2) / TM_TILE_MAXU);
+                const int rest = c->units - t1 * TM_TILE_MAXU;
+                if (t1 >= 1 && rest > 0) {
+                    c->cost_g.t1 = t1; c->cost_g.su1 = TM_TILE_MAXU; c->cost_g.su2 = su2;
+                    c->tiles_g = t1 + (rest + su2 - 1) / su2;
+                }
+            }
+        }
         // the balancer's guarantee is TM_TILE_MAXU units per tile; equal-length likelihood tiles may be longer
         c->cost_l.pad = (c->equal_cost && (long long)c->tiles_l * TM_TILE_MAXU > c->units) ? TM_TILE_MAXU : TM_TILE_MAXU_L;
     }
@@ -587,7 +609,7 @@ static int enqueue(tamcmc_ctx *c, int Nchains, const double *d_params, const dou
     if (!grad) {
         // finalize happens inside the eval launch (last-arriving workgroup per chain)
     } else {
-        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, tm_setup_balances(units, tiles, c->equal_cost, (grad ? c->cost_g : c->cost_l).pad), d_params, p_wt, p_chain_rec, p_aux, p_noise, p_part,
+        rc = tm_launch_backward(c->L, Nchains, units, cells, tiles, tm_setup_balances(units, tiles, c->equal_cost, (grad ? c->cost_g : c->cost_l).pad), c->cost_g, d_params, p_wt, p_chain_rec, p_aux, p_noise, p_part,
                                 p_gmult, p_gnoise, p_cell, p_thdr, p_hser, c->Nvars, c->d_relax, d_grad, d_logL, d_status,
                                 stream);
         if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "backward launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }

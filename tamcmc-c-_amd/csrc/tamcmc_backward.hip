@@ -217,7 +217,7 @@ __device__ __forceinline__ void tm_bw_mult(const TmLayout &L, const TmChain *__r
 #ifndef TM_BW_THREADS
 #define TM_BW_THREADS 512
 #endif
-__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int cells, int uniform_su,
+__global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout L, int tiles, int cells, int uniform_su, TmCostModel geom,
                                                              const double *__restrict__ params,
                                                              const double *__restrict__ Tcoefs,
                                                              const TmChain *__restrict__ chain_rec,
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             // tiles share a start with their successor and are passed over by taking the last).
             const int ua = M.imin >> TM_UNIT_SHIFT, ub = (M.imax - 1) >> TM_UNIT_SHIFT;
             if (uniform_su > 0) {
-                const int su = uniform_su, tA = ua / su, tB = (ub / su < tiles - 1) ? ub / su : tiles - 1;
+                const int su = uniform_su, tA = tm_tile_of_unit(geom, su, ua), tBq = tm_tile_of_unit(geom, su, ub), tB = (tBq < tiles - 1) ? tBq : tiles - 1;
                 const double *G = gmult + (((size_t)chain * tiles + tA) * nm + j) * TM_GSLOTS + sl;
                 const size_t stride = (size_t)nm * TM_GSLOTS;
 #pragma unroll 4
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
             const int t = it >> 1, part = it & 1;
             int u0, u1;
             if (uniform_su > 0) {      // what the setup kernel wrote into the header (tamcmc_setup_body.h)
-                u0 = t * uniform_su; u1 = u0 + uniform_su;
+                u0 = tm_tile_first_unit(geom, uniform_su, t); u1 = u0 + tm_tile_units(geom, uniform_su, t);
                 if (u0 > units) u0 = units;
                 if (u1 > units) u1 = units;
             } else {
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(TM_BW_THREADS) void tamcmc_backward_kernel(TmLayout
 #endif
 }
 
-int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, int equal_cost, const double *d_params,
+int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, int equal_cost, TmCostModel geom, const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise, const TmCellRec *d_cell,
                        const TmTileHdr *d_thdr, const double *d_hser, int Nvars, const int32_t *d_index_to_relax, double *d_grad,
@@ -712,7 +712,7 @@ int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int
     }
     // tiles of equal length (su units each): the tiles a window meets follow by division; else (per-chain boundaries) by search
     const int uniform_su = equal_cost ? 0 : (units + tiles - 1) / tiles;
-    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles, cells, uniform_su,
+    hipLaunchKernelGGL(tamcmc_backward_kernel, dim3(Nchains), dim3(TM_BW_THREADS), lds, (hipStream_t)stream, L, tiles, cells, uniform_su, geom,
                        d_params, d_Tcoefs, static_cast<const TmChain *>(d_chain_rec), static_cast<const TmMultFull *>(d_aux), d_noise,
                        d_part, d_gmult, d_gnoise, d_cell, d_thdr, d_hser, Nvars, d_index_to_relax, d_grad, d_logL, d_status, aux_in_lds);
     return (int)hipGetLastError();

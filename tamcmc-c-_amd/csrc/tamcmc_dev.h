@@ -14,6 +14,11 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
+#define TM_HD __host__ __device__
+#else
+#define TM_HD
+#endif
 
 #define TM_MAXM 7      // components of a multiplet: 2l+1, l <= 3 (build_lorentzian.cpp:74)
 #define TM_MAXH 3      // Harvey profiles per chain (Nnoise = 3*Nharvey+1 = 10 in every .model file, io_ms_global.cpp)
@@ -93,7 +98,9 @@ static_assert(sizeof(TmNoise) == 120, "TmNoise layout");
 #define TM_UNIT_SHIFT 9
 #define TM_CELL_UNITS 8
 #define TM_CELL_SHIFT 3
+#ifndef TM_TILE_MAXU
 #define TM_TILE_MAXU 8      // units per gradient tile at most: 32 KB of weights in LDS; a tile meets at most 2 cells
+#endif
 #define TM_TILE_MAXU_L 16   // units per likelihood-only tile at most (no weights to keep)
 #define TM_EQ_MAXU 4096     // grids of up to this many units (2M bins) get equal-cost tiles (cost prefix lives in LDS)
 
@@ -127,7 +134,14 @@ static_assert(sizeof(TmActive) == 16, "TmActive layout");
 // meets it of (a * ncomp + b).
 struct TmCostModel {
     int32_t c0, a, b, pad;
+    // equal-length tiles of TWO sizes (tail shaping): tiles [0, t1) have su1 units, tiles [t1, tiles) su2 <= su1 units;
+    // t1 = 0: all tiles alike, ceil(units / tiles) units each.  A function of the grid only, like the tile count.
+    int32_t t1, su1, su2, pad2;
 };
+// first unit of tile t / tile holding unit u under that geometry (su = ceil(units / tiles) for the one-size case)
+static inline TM_HD int tm_tile_first_unit(const TmCostModel &g, int su, int t) { return (g.t1 <= 0) ? t * su : (t < g.t1 ? t * g.su1 : g.t1 * g.su1 + (t - g.t1) * g.su2); }
+static inline TM_HD int tm_tile_units(const TmCostModel &g, int su, int t) { return (g.t1 <= 0) ? su : (t < g.t1 ? g.su1 : g.su2); }
+static inline TM_HD int tm_tile_of_unit(const TmCostModel &g, int su, int u) { return (g.t1 <= 0) ? u / su : (u < g.t1 * g.su1 ? u / g.su1 : g.t1 + (u - g.t1 * g.su1) / g.su2); }
 
 struct TmEvalArgs {
     const double *x2, *y, *lx, *isig2;   // x2 = 2 x (the kernels only ever need d = 2x - 2nu), log x, 1 / sigma^2
@@ -177,9 +191,6 @@ static inline int tm_tiles(int units, int grad)
 // and the gradient path's finalize in the backward kernel (built with -ffp-contract=off) give the same bits.
 #define TM_LN2 0.693147180559945309417232
 static __device__ __forceinline__ double tm_tile_logsum(double mant, double e) { return __builtin_fma(e, TM_LN2, log(mant)); }
-#define TM_HD __host__ __device__
-#else
-#define TM_HD
 #endif
 // Whether the setup kernel balances a chain's tiles (per-chain boundaries) or cuts tiles of equal length: the balancer
 // needs slack (tiles * TM_TILE_MAXU > units), its bound is TM_TILE_MAXU units per tile, and its tables live in LDS.
@@ -240,6 +251,7 @@ int tm_launch_eval(const TmEvalArgs &a, int Nchains, bool grad, void *stream);
 int tm_launch_fused(const TmLayout &L, const TmFusedArgs &f, const TmEvalArgs &a, int Nchains, bool grad, void *stream);
 // backward also performs the finalize step (logL, status) of the gradient path
 int tm_launch_backward(const TmLayout &L, int Nchains, int units, int cells, int tiles, int equal_cost /* as given to tm_launch_setup */,
+                       TmCostModel geom /* the cost model / tile geometry given to tm_launch_setup */,
                        const double *d_params,
                        const double *d_Tcoefs, const void *d_chain_rec, const void *d_aux, const TmNoise *d_noise,
                        const double *d_part, const double *d_gmult, const double *d_gnoise, const TmCellRec *d_cell,

@@ -191,7 +191,7 @@ __device__ __forceinline__ void tm_setup_body(const TmLayout &L, const int chain
             int u0 = 0, u1 = 0;
             if (live) {
                 if (eq) { u0 = s_b[tile]; u1 = s_b[tile + 1]; }
-                else { u0 = tile * su; u1 = u0 + su; if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
+                else { u0 = tm_tile_first_unit(cm, su, tile); u1 = u0 + tm_tile_units(cm, su, tile); if (u0 > units) u0 = units; if (u1 > units) u1 = units; }
                 if (u1 - u0 > cm.pad) { u1 = u0 + cm.pad; if (gl == 0) atomicMax(&s_status, 3); }   // cannot happen (see above); never overrun the LDS of the eval kernel
             }
             const int base = u0 << TM_UNIT_SHIFT, end = u1 << TM_UNIT_SHIFT;
