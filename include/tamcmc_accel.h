@@ -31,7 +31,9 @@
  *   TAMCMC_ORDER=0|1|2                launch order (default 2: tile-major, each chain's tiles costliest-first)
  *   TAMCMC_FUSED=0                    one-tile grids: prologue and evaluation as two launches instead of one
  *   TAMCMC_BG_EXACT=1                 Harvey background by exp() per bin instead of the per-cell polynomial
- * (tamcmc_sampler.h: TAMCMC_SAMPLER_THREADS, TAMCMC_SAMPLER_TIMING.)
+ *   TAMCMC_TAIL="frac,su2" | 0        gradient launch on long grids: 8-unit tiles for frac % of the units, su2-unit tiles for the
+ *                                     rest (default "85,4"; 0: all tiles alike); TAMCMC_TAIL_L the same for the likelihood launch (default off)
+ * (tamcmc_sampler.h: TAMCMC_SAMPLER_THREADS, TAMCMC_SAMPLER_TIMING, TAMCMC_SAMPLER_PIPELINE.)
  *
  * Threading: one ctx = one device + one stream; calls on one ctx must be serialised by the caller;
  * different ctx objects (other GPUs, other stars) may be driven concurrently from different threads.

@@ -22,6 +22,11 @@
  * chains owned elsewhere are passed over by a jump-ahead of the generator, not made), so the
  * chains are bit-identical to a single-process run.  A parallel-tempering pair that straddles two ranks
  * is exchanged by the caller (torch.distributed send/recv) through tamcmc_sampler_pt_* below.
+ *
+ * Environment switches read by tamcmc_sampler_create*: TAMCMC_SAMPLER_THREADS (host threads of the per-chain fork-join
+ * pool), TAMCMC_SAMPLER_TIMING=1 (phase times printed at destroy), TAMCMC_SAMPLER_PIPELINE=1 (HIP evaluator, loops in the
+ * library: the local chains as two sub-batches in flight, one handled on the host while the GPU evaluates the other;
+ * same draws and decisions; off by default, measured slower at 64 chains x 1e5 bins).
  */
 #ifndef TAMCMC_SAMPLER_H
 #define TAMCMC_SAMPLER_H

@@ -311,6 +311,21 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
                 }
             }
         }
+        // the same for the likelihood launch (experiment: TAMCMC_TAIL_L="frac,su2"; off by default)
+        c->cost_l.t1 = 0;
+        {
+            const char *e = getenv("TAMCMC_TAIL_L");
+            int frac = 0, su2 = 0;
+            if (e && sscanf(e, "%d,%d", &frac, &su2) == 2 && frac >= 1 && frac <= 99 && su2 >= 1 && su2 <= TM_TILE_MAXU &&
+                c->units >= 70 && !c->equal_cost && !getenv("TAMCMC_TILES")) {
+                const int t1 = (int)(((long long)c->units * frac / 100 + TM_TILE_MAXU / 2) / TM_TILE_MAXU);
+                const int rest = c->units - t1 * TM_TILE_MAXU;
+                if (t1 >= 1 && rest > 0) {
+                    c->cost_l.t1 = t1; c->cost_l.su1 = TM_TILE_MAXU; c->cost_l.su2 = su2;
+                    c->tiles_l = t1 + (rest + su2 - 1) / su2;
+                }
+            }
+        }
         // the balancer's guarantee is TM_TILE_MAXU units per tile; equal-length likelihood tiles may be longer
         c->cost_l.pad = (c->equal_cost && (long long)c->tiles_l * TM_TILE_MAXU > c->units) ? TM_TILE_MAXU : TM_TILE_MAXU_L;
     }

@@ -540,6 +540,19 @@ struct tamcmc_sampler {
     // own sub-batch on its own stream (tamcmc_eval_batch_begin_part).  One half's accept step, next proposals and next
     // launch happen on the host while the GPU evaluates the other half -- chains are independent inside an iteration
     // (MALA.cpp:632-655) and no draw depends on an outcome, so every chain sees exactly the numbers of the plain loop.
+    // ... and the random numbers of the iteration after the next come from a thread of their own (DrawAhead below): with
+    // the GPU hidden behind the host, the draws (a serial stream, ~30 us per iteration at 64 x 44) would otherwise be the
+    // longest item on the host's critical path.  The thread is asked for exactly the packets the plain loop would draw,
+    // one iteration early, and never beyond the last iteration of a call: the stream position on return is the plain
+    // loop's.
+    struct Packet { std::vector<double> u_mh, z_all; double pt_u = 0.0; int32_t pt_A = 0; bool has_pt = false; };
+    Packet packet;                               // what the thread fills: PT draws of iteration j, MH draws of j + 1
+    std::unique_ptr<ChainPool> draw_pool;        // the thread's helpers for the Box-Muller transforms
+    std::thread draw_thread;
+    std::atomic<uint64_t> draw_req{0}, draw_done{0};
+    std::atomic<bool> draw_stop{false};
+    bool draw_req_pt = false;                    // (written before draw_req is bumped) the requested packet has PT draws
+    bool draw_pending = false;                   // a request is outstanding (main thread's view)
     int split = 0;                               // chains in the first half; 0: pipelining off
     bool inflight = false;                       // both halves of iteration `iter` are launched (only inside a run call)
     bool reserved = false;                       // the context's buffers are sized for nloc chains
@@ -615,11 +628,14 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         if (nt < 1) nt = 1;
         s->pool.reset(new ChainPool(nt));
     { const char *e = getenv("TAMCMC_SAMPLER_TIMING"); s->timing = e && e[0] == '1'; }
-    {   // Two halves in flight (pipelined_iteration): OFF unless TAMCMC_SAMPLER_PIPELINE=1.  Measured at 64 chains x 1e5 bins
-        // (profiles/README.md, round 3): the GPU disappears behind the host (wait 1 us per iteration) but the host's own
-        // serial work grows -- four launches instead of two (17 us), two pool forks for the accept step (24 us), and the
-        // priors and the draws of the next iteration (40 us) no longer have a GPU evaluation to hide under: 84 us per
-        // iteration against 65 us with one batch.  It pays only once the draws run on a thread of their own.
+    {   // Two halves in flight (pipelined_iteration) with the draws on a thread of their own: OFF unless
+        // TAMCMC_SAMPLER_PIPELINE=1.  Measured at 64 chains x 1e5 bins, PT every iteration (profiles/README.md, round 3):
+        // without the draw thread the loop is host-bound and SLOWER (84 us per iteration against 65 us with one batch: four
+        // launches instead of two, two pool forks, and the priors and draws with no GPU evaluation left to hide under);
+        // with it 60-62 us (Acquire, +6 %) and 85-90 us (Learning, +-0): the main thread now waits ~26 us per iteration
+        // for the GPU, because a half batch is not half the GPU time -- launch + setup kernel + eval floor are ~33 us from
+        // launch to result against 42 us for the whole batch -- while the host has only ~18 us of work on the other half.
+        // Same draws, same decisions either way (tests/test_sampler_gpu.py).
         const char *e = getenv("TAMCMC_SAMPLER_PIPELINE");
         s->split = (n >= 8 && e && e[0] == '1') ? n / 2 : 0;
     }
@@ -652,6 +668,11 @@ extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s)
         const double k = 1e6 / (double)s->t_iters;
         fprintf(stderr, "[tamcmc sampler] %lld iterations; us per iteration: proposals %.1f, launch %.1f, priors %.1f, draw-ahead %.1f, wait %.1f, accept %.1f\n",
                 (long long)s->t_iters, s->t_phase[0] * k, s->t_phase[1] * k, s->t_phase[2] * k, s->t_phase[3] * k, s->t_phase[4] * k, s->t_phase[5] * k);
+    }
+    if (s && s->draw_thread.joinable()) {
+        s->draw_stop.store(true, std::memory_order_relaxed);
+        s->draw_req.fetch_add(1, std::memory_order_release);
+        s->draw_thread.join();
     }
     delete s;
     return TAMCMC_OK;
@@ -755,15 +776,16 @@ static void skip_foreign(tamcmc_sampler *s, int count)
     s->rng.draw(nv, s->plans[(size_t)n]);
 }
 
-static void draw_mh(tamcmc_sampler *s)
+static void draw_mh(tamcmc_sampler *s, double *u_out = nullptr)
 {
     const int n = s->nloc, nv = s->Nvars, off = s->cfg.chain_offset, N = s->cfg.Nchains;
+    if (!u_out) u_out = s->u_mh.data();
     const bool tm = s->timing && n < N;
     double t0 = tm ? wall_now() : 0.0;
     skip_foreign(s, off);
     if (tm) { const double t1 = wall_now(); s->t_phase[6] += t1 - t0; }
     for (int m = 0; m < n; m++) {
-        s->u_mh[m] = s->rng.uniform();
+        u_out[m] = s->rng.uniform();
         s->rng.draw(nv, s->plans[(size_t)m]);
     }
     if (tm) t0 = wall_now();
@@ -782,7 +804,7 @@ extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s);
 // Proposal of local chain m from its current vars and the normals in z_all: v' = v + chol((Sigma + eps2 I) sigma) z
 // (MALA.cpp:335-353), the factor recomputed only when the proposal parameters changed.  Returns false when the matrix
 // was not positive definite.
-static bool propose_chain(tamcmc_sampler *s, int m)
+static bool propose_chain(tamcmc_sampler *s, int m, bool with_prior = false)
 {
     const int nv = s->Nvars, np = s->Nparams;
     bool ok = true;
@@ -804,6 +826,11 @@ static bool propose_chain(tamcmc_sampler *s, int m)
     }
     std::memcpy(&s->p_prop[(size_t)m * np], &s->params[(size_t)m * np], sizeof(double) * np);
     for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
+    if (with_prior) {       // pipelined loop: the proposal's prior in the same pass (no GPU evaluation left to hide it under)
+        int perr = 0;
+        s->lpr_prop[m] = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+        s->perr_prop[m] = perr;
+    }
     return ok;
 }
 
@@ -833,7 +860,60 @@ static inline void accept_chain(tamcmc_sampler *s, int m, int64_t i, double gamm
     }
     s->Pmove[m] = r;
     if (learn && (i % period) == 0) update_proposal(s, m, gamma, r);
-    if (ahead && !propose_chain(s, m)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
+    if (ahead && !propose_chain(s, m, s->split > 0)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
+}
+
+// ---- the draw thread of the pipelined loop ------------------------------------------------------------------------
+static void draw_packet(tamcmc_sampler *s, bool with_pt, ChainPool *pool)
+{
+    const int n = s->nloc, nv = s->Nvars;
+    tamcmc_sampler::Packet &P = s->packet;
+    P.has_pt = with_pt;
+    if (with_pt) {
+        P.pt_u = s->rng.uniform();                                    // MALA.cpp:384
+        P.pt_A = (int32_t)(s->rng.g.next() % (s->cfg.Nchains - 1));   // :390
+    }
+    draw_mh(s, P.u_mh.data());
+    pool->run(n, [&](int m) { s->plans[m].fill(&P.z_all[(size_t)m * nv]); });
+}
+
+static void draw_thread_main(tamcmc_sampler *s)
+{
+    uint64_t seen = 0;
+    for (;;) {
+        uint64_t r = s->draw_req.load(std::memory_order_acquire);
+        for (int spin = 0; r == seen && !s->draw_stop.load(std::memory_order_relaxed); spin++) {
+            if (spin < 20000) __builtin_ia32_pause(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
+            r = s->draw_req.load(std::memory_order_acquire);
+        }
+        if (s->draw_stop.load(std::memory_order_relaxed)) return;
+        seen = r;
+        draw_packet(s, s->draw_req_pt, s->draw_pool.get());
+        s->draw_done.store(r, std::memory_order_release);
+    }
+}
+
+static void draw_request(tamcmc_sampler *s, bool with_pt)
+{
+    if (!s->draw_thread.joinable()) {
+        s->packet.u_mh.resize((size_t)s->nloc); s->packet.z_all.resize((size_t)s->nloc * s->Nvars);
+        s->draw_pool.reset(new ChainPool(4));
+        s->draw_thread = std::thread(draw_thread_main, s);
+    }
+    s->draw_req_pt = with_pt;
+    s->draw_req.fetch_add(1, std::memory_order_release);
+    s->draw_pending = true;
+}
+
+// the requested packet becomes the sampler's current draws (u_mh / z_all of the coming iteration, PT draws of this one)
+static void draw_collect(tamcmc_sampler *s)
+{
+    const uint64_t want = s->draw_req.load(std::memory_order_relaxed);
+    while (s->draw_done.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+    s->draw_pending = false;
+    std::swap(s->u_mh, s->packet.u_mh);
+    std::swap(s->z_all, s->packet.z_all);
+    if (s->packet.has_pt) { s->pt_u = s->packet.pt_u; s->pt_A = s->packet.pt_A; s->pt_cached = true; }
 }
 
 static void drain_parts(tamcmc_sampler *s)
@@ -872,7 +952,13 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
         }
         s->drawn_ahead = false;
         if (!s->proposed_ahead)
-            s->pool->run(n, [&](int m) { if (!propose_chain(s, m)) bad.fetch_add(1, std::memory_order_relaxed); });
+            s->pool->run(n, [&](int m) { if (!propose_chain(s, m, true)) bad.fetch_add(1, std::memory_order_relaxed); });
+        else      // proposals made by the plain loop (mh_step) carry no prior yet
+            s->pool->run(n, [&](int m) {
+                int perr = 0;
+                s->lpr_prop[m] = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
+                s->perr_prop[m] = perr;
+            });
         s->proposed_ahead = false;
         t1 = now(); s->t_phase[0] += t1 - t0; t0 = t1;
         rc = launch(0);
@@ -883,20 +969,24 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
     s->inflight = true;
     bad.fetch_add(s->bad_chol_ahead.exchange(0), std::memory_order_relaxed);
     s->bad_chol += bad.load();
-    // while the GPU works: priors of the proposals in flight, then the stream one iteration ahead (the parallel-tempering
-    // draws of THIS iteration come first in it, MALA.cpp:384,390)
+    // The stream one iteration ahead: the parallel-tempering draws of THIS iteration (they come first, MALA.cpp:384,390),
+    // then the MH draws of the next.  From the draw thread if it was asked for them during the previous iteration, else
+    // made here (first iteration of a call); the packet after that is requested at once, unless this call ends first.
     s->u_now = s->u_mh;
-    s->pool->run(n, [&](int m) {
-        int perr = 0;
-        s->lpr_prop[m] = (double)log_prior(s->prior, &s->p_prop[(size_t)m * np], &perr);
-        s->perr_prop[m] = perr;
-    });
-    t1 = now(); s->t_phase[2] += t1 - t0; t0 = t1;
     const bool due = tamcmc_sampler_pt_due(s) != 0;
-    if (due && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
-    draw_mh(s);
-    s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+    if (s->draw_pending) {
+        draw_collect(s);
+    } else {
+        if (due && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
+        draw_mh(s);
+        s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+    }
     s->drawn_ahead = true;
+    if (launch_next) {
+        const int64_t inext = i + 1;
+        const bool due_next = s->cfg.dN_mixing > 0 && s->cfg.Nchains >= 2 && (inext % s->cfg.dN_mixing == 0) && inext != 0;
+        draw_request(s, due_next);
+    }
     t1 = now(); s->t_phase[3] += t1 - t0; t0 = t1;
 
     // the half holding the local chain(s) of the drawn pair goes first; a pair with one chain in each half needs both
@@ -922,6 +1012,7 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
         return (int)TAMCMC_OK;
     };
     auto fail = [&](int code, int pending_half) {      // leave nothing in flight behind an error
+        if (s->draw_pending) draw_collect(s);
         if (pending_half >= 0) { std::vector<double> l((size_t)n); (void)tamcmc_eval_batch_end_part(s->hip_ctx, pending_half, l.data(), nullptr); }
         s->inflight = false; s->proposed_ahead = false;
         return code;
@@ -961,7 +1052,7 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
         t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
     }
     s->t_iters++;
-    if (perr_any.load()) { if (s->inflight) drain_parts(s); s->proposed_ahead = false; return TAMCMC_E_INVALID; }
+    if (perr_any.load()) { if (s->draw_pending) draw_collect(s); if (s->inflight) drain_parts(s); s->proposed_ahead = false; return TAMCMC_E_INVALID; }
     return TAMCMC_OK;
 }
 
@@ -1097,8 +1188,8 @@ static void pt_apply(tamcmc_sampler *s, int A, double u, const double *recA, con
     }
     if (sw && s->proposed_ahead) {      // the proposals computed ahead started from the rows just replaced
         const int a = A - off, b = B - off;
-        if (a >= 0 && a < s->nloc && !propose_chain(s, a)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
-        if (b >= 0 && b < s->nloc && !propose_chain(s, b)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
+        if (a >= 0 && a < s->nloc && !propose_chain(s, a, s->split > 0)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
+        if (b >= 0 && b < s->nloc && !propose_chain(s, b, s->split > 0)) s->bad_chol_ahead.fetch_add(1, std::memory_order_relaxed);
     }
     if (swapped) *swapped = sw ? 1 : 0;
     if (r_out) *r_out = r_T;
