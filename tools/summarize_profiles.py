@@ -55,12 +55,12 @@ def main(out_dir):
             d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
     json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     # the condensed file bench.py reads for roofline.traffic / roofline.valu
-    def pick(suffix):
-        for k in res:
-            if k.startswith("tamcmc_eval_kernel") and k.endswith(suffix):
-                return k
-        return None
-    kg, kf = pick("true>"), pick("false>")
+    def pick(prefix):
+        # tamcmc_eval_kernel<GRAD, GEN>: the variant with the most launches (the bench's; a one-off model_explicit launch
+        # uses the generic variant)
+        c = [k for k in res if k.startswith(prefix)]
+        return max(c, key=lambda k: res[k].get("launches", 0)) if c else None
+    kg, kf = pick("tamcmc_eval_kernel<true"), pick("tamcmc_eval_kernel<false")
     if kg and kf and "hbm_bytes_per_launch" in res[kg] and "SQ_INSTS_VALU" in res[kg]:
         hb = {"source": "%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, "
                         "64 chains x 1e5 bins)" % os.path.basename(os.path.normpath(out_dir)),
