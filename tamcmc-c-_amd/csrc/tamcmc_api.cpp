@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "tamcmc_accel.h"
@@ -50,6 +51,7 @@ struct tamcmc_ctx {
     // per-batch buffers (capacity in chains)
     int cap = 0;
     bool cap_grad = false;
+    void *d_slab = nullptr;        // one allocation behind every per-batch buffer below (ensure_capacity)
     double *d_params = nullptr, *d_T = nullptr, *d_logL = nullptr, *d_part = nullptr;
     double *d_gmult = nullptr, *d_gnoise = nullptr, *d_hser = nullptr;
     int32_t *d_order = nullptr; int order_mode = 2;
@@ -178,17 +180,15 @@ static int build_layout(TmLayout &L, int model_case, int likelihood_case, double
     return TAMCMC_OK;
 }
 
+// The per-batch buffers live in ONE allocation (a slab, carved at 256-byte boundaries): the kernels of a step touch a
+// dozen of them within their first microseconds, and every separate hipMalloc sits in pages of its own.
 static void free_batch(tamcmc_ctx *c)
 {
-    (void)hipFree(c->d_params); (void)hipFree(c->d_T); (void)hipFree(c->d_logL); (void)hipFree(c->d_part);
-    (void)hipFree(c->d_gmult); (void)hipFree(c->d_gnoise); (void)hipFree(c->d_hser); (void)hipFree(c->d_order); c->d_order = nullptr;
-    (void)hipFree(c->d_status); (void)hipFree(c->d_rows); (void)hipFree(c->d_mult); (void)hipFree(c->d_noise);
-    (void)hipFree(c->d_chain_rec); (void)hipFree(c->d_aux); c->d_chain_rec = c->d_aux = nullptr;
-    (void)hipFree(c->d_cell); (void)hipFree(c->d_thdr); (void)hipFree(c->d_tidx); c->d_cell = nullptr; c->d_thdr = nullptr; c->d_tidx = nullptr;
-    (void)hipFree(c->d_ticket); c->d_ticket = nullptr;
-    (void)hipFree(c->d_wt); c->d_wt = nullptr;
-    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_hser = nullptr;
-    c->d_status = c->d_rows = nullptr; c->d_mult = nullptr; c->d_noise = nullptr;
+    (void)hipFree(c->d_slab); c->d_slab = nullptr;
+    c->d_params = c->d_T = c->d_logL = c->d_part = c->d_gmult = c->d_gnoise = c->d_hser = c->d_wt = nullptr;
+    c->d_status = c->d_rows = c->d_order = c->d_ticket = nullptr;
+    c->d_mult = nullptr; c->d_noise = nullptr; c->d_cell = nullptr; c->d_thdr = nullptr; c->d_tidx = nullptr;
+    c->d_chain_rec = c->d_aux = nullptr;
     c->cap = 0; c->cap_grad = false;
 }
 
@@ -201,29 +201,46 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     if (c->part_stream) TM_HIP(hipStreamSynchronize(c->part_stream));
     free_batch(c);
     const size_t n = (size_t)cap;
-    const int nm = c->L.n_mult > 0 ? c->L.n_mult : 1;
-    TM_HIP(hipMalloc(&c->d_params, n * c->L.Nparams * sizeof(double)));
-    TM_HIP(hipMalloc(&c->d_T, n * sizeof(double)));
-    TM_HIP(hipMalloc(&c->d_logL, n * sizeof(double)));
-    TM_HIP(hipMalloc(&c->d_part, n * c->tiles_max * 4 * sizeof(double)));
-    TM_HIP(hipMalloc(&c->d_status, n * sizeof(int32_t)));
-    TM_HIP(hipMalloc(&c->d_rows, n * sizeof(int32_t)));
-    TM_HIP(hipMalloc(&c->d_mult, n * nm * sizeof(TmMult)));
-    TM_HIP(hipMalloc(&c->d_noise, n * sizeof(TmNoise)));
-    TM_HIP(hipMalloc(&c->d_wt, n * 2 * sizeof(double)));
-    TM_HIP(hipMalloc(&c->d_ticket, n * sizeof(int32_t)));
+    const size_t nm = (size_t)(c->L.n_mult > 0 ? c->L.n_mult : 1);
+    // two passes over the same list: sizes first, then the pointers
+    char *base = nullptr;
+    size_t off = 0;
+    auto carve = [&](auto **ptr, size_t bytes) {
+        if (base) *ptr = reinterpret_cast<std::remove_reference_t<decltype(**ptr)> *>(base + off);
+        off += (bytes + 255) & ~(size_t)255;
+    };
+    auto layout = [&]() {
+        off = 0;
+        carve(&c->d_params, n * c->L.Nparams * sizeof(double));
+        carve(&c->d_T, n * sizeof(double));
+        carve(&c->d_logL, n * sizeof(double));
+        carve(&c->d_wt, n * 2 * sizeof(double));
+        carve(&c->d_status, n * sizeof(int32_t));
+        carve(&c->d_rows, n * sizeof(int32_t));
+        carve(&c->d_ticket, n * sizeof(int32_t));
+        carve(&c->d_noise, n * sizeof(TmNoise));
+        carve(&c->d_order, n * c->tiles_max * sizeof(int32_t));
+        carve(&c->d_thdr, n * c->tiles_max * sizeof(TmTileHdr));
+        carve(&c->d_part, n * c->tiles_max * 4 * sizeof(double));
+        carve(&c->d_cell, n * c->cells * sizeof(TmCellRec));
+        carve(&c->d_mult, n * nm * sizeof(TmMult));
+        carve(&c->d_tidx, n * c->tiles_max * nm * sizeof(TmActive));
+        if (g) {
+            char *cr = nullptr, *ax = nullptr;
+            carve(&cr, n * tm_sizeof_chain_rec());
+            carve(&ax, n * nm * tm_sizeof_aux());
+            if (base) { c->d_chain_rec = cr; c->d_aux = ax; }
+            carve(&c->d_gnoise, n * c->tiles_g * 2 * TM_NSLOTS * sizeof(double));
+            carve(&c->d_hser, n * c->cells * TM_MAXH * TM_HSER * sizeof(double));
+            carve(&c->d_gmult, n * c->tiles_g * nm * TM_GSLOTS * sizeof(double));
+        }
+    };
+    layout();
+    const size_t total = off;
+    if (hipMalloc(&c->d_slab, total) != hipSuccess) { c->d_slab = nullptr; free_batch(c); return TAMCMC_E_NOMEM; }
+    base = static_cast<char *>(c->d_slab);
+    layout();
     TM_HIP(hipMemset(c->d_ticket, 0, n * sizeof(int32_t)));
-    TM_HIP(hipMalloc(&c->d_cell, n * c->cells * sizeof(TmCellRec)));
-    TM_HIP(hipMalloc(&c->d_thdr, n * c->tiles_max * sizeof(TmTileHdr)));
-    TM_HIP(hipMalloc(&c->d_tidx, n * c->tiles_max * nm * sizeof(TmActive)));
-    TM_HIP(hipMalloc(&c->d_order, n * c->tiles_max * sizeof(int32_t)));
-    if (g) {
-        TM_HIP(hipMalloc(&c->d_gmult, n * c->tiles_g * nm * TM_GSLOTS * sizeof(double)));
-        TM_HIP(hipMalloc(&c->d_gnoise, n * c->tiles_g * 2 * TM_NSLOTS * sizeof(double)));
-        TM_HIP(hipMalloc(&c->d_hser, n * c->cells * TM_MAXH * TM_HSER * sizeof(double)));
-        TM_HIP(hipMalloc(&c->d_chain_rec, n * tm_sizeof_chain_rec()));
-        TM_HIP(hipMalloc(&c->d_aux, n * nm * tm_sizeof_aux()));
-    }
     c->cap = cap;
     c->cap_grad = g;
     return TAMCMC_OK;
