@@ -132,10 +132,12 @@ int tamcmc_eval_batch_device(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams,
 int tamcmc_eval_batch_begin(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs);
 int tamcmc_eval_batch_end(tamcmc_ctx *ctx, int32_t Nchains, double *logL, int32_t *status);
 
-/* The same in two PARTS that may be in flight together (part = 0 or 1; part 1 runs on a stream of its own): chains
- * [first, first + Nchains) of the context's numbering -- the ranges of two parts in flight must not overlap; with several
- * spectra resident `first` also indexes the chain -> spectrum map.  For a sampler that splits its chains in two halves
- * and handles one half's results on the host while the GPU evaluates the other (chains are independent inside an
+#define TAMCMC_MAX_PARTS 4
+/* The same in up to TAMCMC_MAX_PARTS PARTS that may be in flight together (part = 0 .. 3; every part but 0 runs on a stream
+ * of its own): chains
+ * [first, first + Nchains) of the context's numbering -- the ranges of parts in flight must not overlap; with several
+ * spectra resident `first` also indexes the chain -> spectrum map.  For a sampler that splits its chains in parts
+ * and handles one part's results on the host while the GPU evaluates the others (chains are independent inside an
  * iteration, MALA.cpp:632-655).  params / Tcoefs point at the part's first row / entry.  A chain's result is bit for
  * bit that of tamcmc_eval_batch (tests/test_parity_gpu.py).  tamcmc_ctx_reserve sizes the context's buffers for Nchains
  * chains in total beforehand: they are never reallocated under a part in flight (a begin that would need to returns

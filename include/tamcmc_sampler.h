@@ -24,7 +24,7 @@
  * is exchanged by the caller (torch.distributed send/recv) through tamcmc_sampler_pt_* below.
  *
  * Environment switches read by tamcmc_sampler_create*: TAMCMC_SAMPLER_THREADS (host threads of the per-chain fork-join
- * pool), TAMCMC_SAMPLER_TIMING=1 (phase times printed at destroy), TAMCMC_SAMPLER_PIPELINE=1 (HIP evaluator, loops in the
+ * pool), TAMCMC_SAMPLER_TIMING=1 (phase times printed at destroy), TAMCMC_SAMPLER_PIPELINE=2 (HIP evaluator, loops in the
  * library: the local chains as two sub-batches in flight, one handled on the host while the GPU evaluates the other;
  * same draws and decisions; off by default, measured slower at 64 chains x 1e5 bins).
  */

@@ -79,10 +79,11 @@ struct tamcmc_ctx {
     int in_flight = 0;             // chains of a tamcmc_eval_batch_begin not yet collected by _end
     // tamcmc_eval_batch_begin_part / _end_part: two sub-batches of the context's chains in flight at once, part 1 on a
     // stream of its own; a part's rows of every per-chain buffer start at its first chain
-    hipStream_t part_stream = nullptr;
-    int part_first[2] = {0, 0}, part_n[2] = {0, 0};
-    bool part_ev_recorded[2] = {false, false};
-    hipEvent_t part_ev[2] = {nullptr, nullptr};
+    hipStream_t part_streams[TAMCMC_MAX_PARTS] = {};      // [0] unused (part 0 runs on the context stream), created on demand
+    int part_first[TAMCMC_MAX_PARTS] = {}, part_n[TAMCMC_MAX_PARTS] = {};
+    bool part_ev_recorded[TAMCMC_MAX_PARTS] = {};
+    hipEvent_t part_ev[TAMCMC_MAX_PARTS] = {};
+    bool parts_busy() const { for (int n : part_n) if (n) return true; return false; }
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
@@ -198,7 +199,7 @@ static int ensure_capacity(tamcmc_ctx *c, int Nchains, bool grad)
     const int cap = Nchains > c->cap ? Nchains : c->cap;
     const bool g = grad || c->cap_grad;
     TM_HIP(hipStreamSynchronize(c->stream));
-    if (c->part_stream) TM_HIP(hipStreamSynchronize(c->part_stream));
+    for (hipStream_t ps : c->part_streams) if (ps) TM_HIP(hipStreamSynchronize(ps));
     free_batch(c);
     const size_t n = (size_t)cap;
     const size_t nm = (size_t)(c->L.n_mult > 0 ? c->L.n_mult : 1);
@@ -384,7 +385,7 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
     if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
     (void)hipHostFree(c->h_probe);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    if (c->part_stream) { (void)hipStreamSynchronize(c->part_stream); (void)hipStreamDestroy(c->part_stream); }
+    for (hipStream_t ps : c->part_streams) if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -660,7 +661,7 @@ extern "C" int tamcmc_eval_batch_device(tamcmc_ctx *c, int32_t Nchains, int32_t 
                                         double *d_logL, double *d_grad, int32_t *d_status)
 {
     if (!c || Nchains < 1 || !d_params || !d_Tcoefs || !d_logL) return TAMCMC_E_INVALID;
-    if (Nparams != c->L.Nparams || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;
+    if (Nparams != c->L.Nparams || c->parts_busy()) return TAMCMC_E_INVALID;
     if (d_grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, d_grad != nullptr);
@@ -766,7 +767,7 @@ static int ensure_staging(tamcmc_ctx *c, int Nchains)
 
 extern "C" int tamcmc_eval_batch_begin(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs)
 {
-    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;
+    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight || c->parts_busy()) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, false);
     if (rc != TAMCMC_OK) return rc;
@@ -798,9 +799,8 @@ extern "C" int tamcmc_eval_batch_end(tamcmc_ctx *c, int32_t Nchains, double *log
 
 extern "C" int tamcmc_ctx_reserve(tamcmc_ctx *c, int32_t Nchains)
 {
-    if (!c || Nchains < 1 || c->in_flight || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;
+    if (!c || Nchains < 1 || c->in_flight || c->parts_busy()) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
-    if (c->part_stream) TM_HIP(hipStreamSynchronize(c->part_stream));
     int rc = ensure_capacity(c, Nchains, false);
     if (rc != TAMCMC_OK) return rc;
     return ensure_staging(c, Nchains);
@@ -809,19 +809,19 @@ extern "C" int tamcmc_ctx_reserve(tamcmc_ctx *c, int32_t Nchains)
 extern "C" int tamcmc_eval_batch_begin_part(tamcmc_ctx *c, int32_t part, int32_t first, int32_t Nchains, int32_t Nparams,
                                             const double *params, const double *Tcoefs)
 {
-    if (!c || part < 0 || part > 1 || first < 0 || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams) return TAMCMC_E_INVALID;
+    if (!c || part < 0 || part >= TAMCMC_MAX_PARTS || first < 0 || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams) return TAMCMC_E_INVALID;
     if (c->in_flight || c->part_n[part]) return TAMCMC_E_INVALID;
-    const int other = 1 - part;
-    if (c->part_n[other] && first < c->part_first[other] + c->part_n[other] && c->part_first[other] < first + Nchains) return TAMCMC_E_INVALID;   // overlap
+    for (int o = 0; o < TAMCMC_MAX_PARTS; o++)      // ranges of parts in flight must not overlap
+        if (o != part && c->part_n[o] && first < c->part_first[o] + c->part_n[o] && c->part_first[o] < first + Nchains) return TAMCMC_E_INVALID;
     // buffers are never (re)allocated under a part in flight: tamcmc_ctx_reserve sizes them beforehand
     if (first + Nchains > c->cap || first + Nchains > c->h_cap || c->h_nvars != c->Nvars) {
-        if (c->part_n[other]) return TAMCMC_E_INVALID;
+        if (c->parts_busy()) return TAMCMC_E_INVALID;
         const int rc = tamcmc_ctx_reserve(c, first + Nchains);
         if (rc != TAMCMC_OK) return rc;
     }
     TM_HIP(hipSetDevice(c->device));
-    if (part == 1 && !c->part_stream) TM_HIP(hipStreamCreateWithFlags(&c->part_stream, hipStreamNonBlocking));
-    hipStream_t stream = (part == 0) ? c->stream : c->part_stream;
+    if (part > 0 && !c->part_streams[part]) TM_HIP(hipStreamCreateWithFlags(&c->part_streams[part], hipStreamNonBlocking));
+    hipStream_t stream = (part == 0) ? c->stream : c->part_streams[part];
     const size_t f = (size_t)first, n = (size_t)Nchains, np = (size_t)Nparams, hc = (size_t)c->h_cap;
     std::memcpy(c->h_in + f * np, params, n * np * sizeof(double));
     std::memcpy(c->h_in + hc * np + f, Tcoefs, n * sizeof(double));
@@ -837,10 +837,10 @@ extern "C" int tamcmc_eval_batch_begin_part(tamcmc_ctx *c, int32_t part, int32_t
 
 extern "C" int tamcmc_eval_batch_end_part(tamcmc_ctx *c, int32_t part, double *logL, int32_t *status)
 {
-    if (!c || part < 0 || part > 1 || !logL || !c->part_n[part]) return TAMCMC_E_INVALID;
+    if (!c || part < 0 || part >= TAMCMC_MAX_PARTS || !logL || !c->part_n[part]) return TAMCMC_E_INVALID;
     const int n = c->part_n[part], first = c->part_first[part];
     c->part_n[part] = 0;
-    hipStream_t stream = (part == 0) ? c->stream : c->part_stream;
+    hipStream_t stream = (part == 0) ? c->stream : c->part_streams[part];
     const int rc = wait_slots(c, reinterpret_cast<volatile const uint64_t *>(c->h_out) + first, c->h_status + first, n, (size_t)n,
                               &c->part_ev[part], &c->part_ev_recorded[part], stream, c->d_ticket + first, n);
     if (rc != TAMCMC_OK) return rc;
@@ -861,7 +861,7 @@ extern "C" int tamcmc_eval_batch(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams
     for (int r = 0; r < n_rows; r++)
         if (model_rows[r] < 0 || model_rows[r] >= Nchains) return TAMCMC_E_INVALID;
     if (grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }
-    if (c->in_flight || c->part_n[0] || c->part_n[1]) return TAMCMC_E_INVALID;   // (buffers may move below)
+    if (c->in_flight || c->parts_busy()) return TAMCMC_E_INVALID;   // (buffers may move below)
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, grad != nullptr);
     if (rc != TAMCMC_OK) return rc;

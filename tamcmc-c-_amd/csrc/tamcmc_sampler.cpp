@@ -553,7 +553,8 @@ struct tamcmc_sampler {
     std::atomic<bool> draw_stop{false};
     bool draw_req_pt = false;                    // (written before draw_req is bumped) the requested packet has PT draws
     bool draw_pending = false;                   // a request is outstanding (main thread's view)
-    int split = 0;                               // chains in the first half; 0: pipelining off
+    int split = 0;                               // > 0: pipelining on (chains per part, rounded up)
+    int nparts = 0;                              // sub-batches in flight (2 .. TAMCMC_MAX_PARTS)
     bool inflight = false;                       // both halves of iteration `iter` are launched (only inside a run call)
     bool reserved = false;                       // the context's buffers are sized for nloc chains
     std::atomic<int64_t> bad_chol_ahead{0};
@@ -635,9 +636,16 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         // with it 60-62 us (Acquire, +6 %) and 85-90 us (Learning, +-0): the main thread now waits ~26 us per iteration
         // for the GPU, because a half batch is not half the GPU time -- launch + setup kernel + eval floor are ~33 us from
         // launch to result against 42 us for the whole batch -- while the host has only ~18 us of work on the other half.
+        // More parts make it worse (3: 74 us, 4: 85 us per Acquire iteration): every part costs two launches (8-9 us of
+        // host time) and a pool fork (~10 us whatever the number of chains on this host).
         // Same draws, same decisions either way (tests/test_sampler_gpu.py).
-        const char *e = getenv("TAMCMC_SAMPLER_PIPELINE");
-        s->split = (n >= 8 && e && e[0] == '1') ? n / 2 : 0;
+        const char *e = getenv("TAMCMC_SAMPLER_PIPELINE");      // 1: two parts; 2 .. TAMCMC_MAX_PARTS: that many
+        int parts = e ? atoi(e) : 0;
+        if (parts == 1) parts = 2;
+        if (parts > TAMCMC_MAX_PARTS) parts = TAMCMC_MAX_PARTS;
+        if (n < 4 * parts) parts = 0;
+        s->nparts = parts;
+        s->split = parts > 0 ? (n + parts - 1) / parts : 0;
     }
     }
     s->rng.g.seed(cfg->seed);
@@ -920,8 +928,7 @@ static void drain_parts(tamcmc_sampler *s)
 {
     if (!s->inflight) return;
     std::vector<double> l((size_t)s->nloc);
-    (void)tamcmc_eval_batch_end_part(s->hip_ctx, 0, l.data(), nullptr);
-    (void)tamcmc_eval_batch_end_part(s->hip_ctx, 1, l.data(), nullptr);
+    for (int q = 0; q < s->nparts; q++) (void)tamcmc_eval_batch_end_part(s->hip_ctx, q, l.data(), nullptr);   // (parts not in flight: refused, harmless)
     s->inflight = false;
 }
 
@@ -932,19 +939,29 @@ static void drain_parts(tamcmc_sampler *s)
 template <class PT>
 static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *moved_row, PT &&pt_step)
 {
-    const int n = s->nloc, nv = s->Nvars, np = s->Nparams, off = s->cfg.chain_offset, h = s->split;
+    const int n = s->nloc, nv = s->Nvars, np = s->Nparams, off = s->cfg.chain_offset, P = s->nparts;
     const int64_t i = s->iter;
     const double gamma = s->cfg.c0 / (1. + (double)i);             // MALA.cpp:630
     auto now = [&]() { return s->timing ? wall_now() : 0.0; };
     double t0 = now(), t1;
-    const int m0[2] = {0, h}, cnt[2] = {h, n - h};
-    auto launch = [&](int hh) {
-        return tamcmc_eval_batch_begin_part(s->hip_ctx, hh, m0[hh], cnt[hh], np, &s->p_prop[(size_t)m0[hh] * np], &s->T[off + m0[hh]]);
+    int m0[TAMCMC_MAX_PARTS + 1];
+    for (int q = 0; q <= P; q++) m0[q] = (int)(((long long)q * n) / P);     // part q = chains [m0[q], m0[q + 1])
+    auto part_of = [&](int m) { int q = 0; while (q + 1 < P && m >= m0[q + 1]) q++; return q; };
+    auto launch = [&](int q) {
+        return tamcmc_eval_batch_begin_part(s->hip_ctx, q, m0[q], m0[q + 1] - m0[q], np, &s->p_prop[(size_t)m0[q] * np], &s->T[off + m0[q]]);
+    };
+    bool flying[TAMCMC_MAX_PARTS] = {};
+    auto fail = [&](int code) {      // leave nothing in flight behind an error
+        if (s->draw_pending) draw_collect(s);
+        std::vector<double> l((size_t)n);
+        for (int q = 0; q < P; q++) if (flying[q]) (void)tamcmc_eval_batch_end_part(s->hip_ctx, q, l.data(), nullptr);
+        s->inflight = false; s->proposed_ahead = false;
+        return code;
     };
     int rc = TAMCMC_OK;
     std::atomic<int64_t> bad{0};
     if (!s->inflight) {
-        // pipeline start: this iteration's draws and proposals (unless made ahead), both halves launched
+        // pipeline start: this iteration's draws and proposals (unless made ahead), every part launched
         if (!s->reserved) { rc = tamcmc_ctx_reserve(s->hip_ctx, n); if (rc != TAMCMC_OK) return rc; s->reserved = true; }
         if (!s->drawn_ahead) {
             draw_mh(s);
@@ -961,10 +978,10 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
             });
         s->proposed_ahead = false;
         t1 = now(); s->t_phase[0] += t1 - t0; t0 = t1;
-        rc = launch(0);
-        if (rc == TAMCMC_OK) { rc = launch(1); if (rc != TAMCMC_OK) { s->inflight = true; drain_parts(s); } }
-        if (rc != TAMCMC_OK) return rc;
+        for (int q = 0; q < P; q++) { rc = launch(q); if (rc != TAMCMC_OK) return fail(rc); flying[q] = true; }
         t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+    } else {
+        for (int q = 0; q < P; q++) flying[q] = true;
     }
     s->inflight = true;
     bad.fetch_add(s->bad_chol_ahead.exchange(0), std::memory_order_relaxed);
@@ -989,67 +1006,64 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
     }
     t1 = now(); s->t_phase[3] += t1 - t0; t0 = t1;
 
-    // the half holding the local chain(s) of the drawn pair goes first; a pair with one chain in each half needs both
-    int first = 0;
-    bool together = false, local = false;
+    // Order of the parts: the one(s) holding the local chain(s) of the drawn pair first -- their accept step, the swap,
+    // their relaunch -- then the others in turn.  A pair with a chain in each of two parts needs both before the swap.
+    int pa = -1, pb = -1;                                 // parts of the pair's local chains (pb: second part, or -1)
     if (due) {
         const int a = s->pt_A - off, b = a + 1;
         const bool inA = a >= 0 && a < n, inB = b >= 0 && b < n;
-        local = inA || inB;
-        if (inA && inB && (a < h) != (b < h)) together = true;
-        else if (local) first = ((inA ? a : b) < h) ? 0 : 1;
+        if (inA) pa = part_of(a);
+        if (inB) { const int q = part_of(b); if (pa < 0) pa = q; else if (q != pa) pb = q; }
     }
     int64_t period = 1;
     const bool learn = learning_now(s, i, &period);
     std::atomic<int> perr_any{0};
-    auto finish_half = [&](int hh) {
-        int r = tamcmc_eval_batch_end_part(s->hip_ctx, hh, &s->L_prop[(size_t)m0[hh]], &s->status[(size_t)m0[hh]]);
+    auto finish = [&](int q) {
+        int r = tamcmc_eval_batch_end_part(s->hip_ctx, q, &s->L_prop[(size_t)m0[q]], &s->status[(size_t)m0[q]]);
+        flying[q] = false;
         t1 = now(); s->t_phase[4] += t1 - t0; t0 = t1;
         if (r != TAMCMC_OK) return r;
-        s->pool->run(cnt[hh], [&](int k) { accept_chain(s, m0[hh] + k, i, gamma, learn, period, true, perr_any); });
-        if (moved_row) std::memcpy(moved_row + m0[hh], &s->moved[(size_t)m0[hh]], (size_t)cnt[hh]);
+        s->pool->run(m0[q + 1] - m0[q], [&](int k) { accept_chain(s, m0[q] + k, i, gamma, learn, period, true, perr_any); });
+        if (moved_row) std::memcpy(moved_row + m0[q], &s->moved[(size_t)m0[q]], (size_t)(m0[q + 1] - m0[q]));
         t1 = now(); s->t_phase[5] += t1 - t0; t0 = t1;
         return (int)TAMCMC_OK;
     };
-    auto fail = [&](int code, int pending_half) {      // leave nothing in flight behind an error
-        if (s->draw_pending) draw_collect(s);
-        if (pending_half >= 0) { std::vector<double> l((size_t)n); (void)tamcmc_eval_batch_end_part(s->hip_ctx, pending_half, l.data(), nullptr); }
-        s->inflight = false; s->proposed_ahead = false;
-        return code;
+    auto relaunch = [&](int q) {
+        const int r = launch(q);
+        if (r == TAMCMC_OK) flying[q] = true;
+        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+        return r;
     };
-    if (together || !launch_next) {
-        // (also the last iteration of a call: nothing is launched ahead, so nothing is gained by splitting the host work)
-        rc = finish_half(0);
-        if (rc != TAMCMC_OK) return fail(rc, 1);
-        rc = finish_half(1);
-        if (rc != TAMCMC_OK) return fail(rc, -1);
+    bool pt_done = false;
+    if (!launch_next) {
+        // last iteration of a call: nothing is launched ahead
+        for (int q = 0; q < P; q++) { rc = finish(q); if (rc != TAMCMC_OK) return fail(rc); }
         s->inflight = false;
         s->proposed_ahead = true;
         rc = pt_step();
-        if (rc != TAMCMC_OK) return fail(rc, -1);
-        if (launch_next) {
-            rc = launch(0);
-            if (rc == TAMCMC_OK) { rc = launch(1); if (rc != TAMCMC_OK) return fail(rc, 0); }
-            else return fail(rc, -1);
-            s->inflight = true; s->proposed_ahead = false;
-            t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
-        }
+        if (rc != TAMCMC_OK) return fail(rc);
     } else {
-        const int second = 1 - first;
-        rc = finish_half(first);
-        if (rc != TAMCMC_OK) return fail(rc, second);
-        s->proposed_ahead = true;                       // (for the pair's chains: a swap re-proposes them, pt_apply)
-        if (local) { rc = pt_step(); if (rc != TAMCMC_OK) return fail(rc, second); }
-        rc = launch(first);
-        if (rc != TAMCMC_OK) return fail(rc, second);
-        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
-        rc = finish_half(second);
-        if (rc != TAMCMC_OK) return fail(rc, first);
-        if (!local) { rc = pt_step(); if (rc != TAMCMC_OK) return fail(rc, first); }
-        rc = launch(second);
-        if (rc != TAMCMC_OK) return fail(rc, first);
+        if (pa >= 0) {
+            rc = finish(pa);
+            if (rc != TAMCMC_OK) return fail(rc);
+            if (pb >= 0) { rc = finish(pb); if (rc != TAMCMC_OK) return fail(rc); }
+            s->proposed_ahead = true;                   // (for the pair's chains: a swap re-proposes them, pt_apply)
+            rc = pt_step();
+            pt_done = true;
+            if (rc != TAMCMC_OK) return fail(rc);
+            rc = relaunch(pa);
+            if (rc != TAMCMC_OK) return fail(rc);
+            if (pb >= 0) { rc = relaunch(pb); if (rc != TAMCMC_OK) return fail(rc); }
+        }
+        for (int q = 0; q < P; q++) {
+            if (q == pa || q == pb) continue;
+            rc = finish(q);
+            if (rc != TAMCMC_OK) return fail(rc);
+            rc = relaunch(q);
+            if (rc != TAMCMC_OK) return fail(rc);
+        }
+        if (!pt_done) { rc = pt_step(); if (rc != TAMCMC_OK) return fail(rc); }   // no local chain in the pair (or no attempt): bookkeeping only
         s->inflight = true; s->proposed_ahead = false;
-        t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
     }
     s->t_iters++;
     if (perr_any.load()) { if (s->draw_pending) draw_collect(s); if (s->inflight) drain_parts(s); s->proposed_ahead = false; return TAMCMC_E_INVALID; }

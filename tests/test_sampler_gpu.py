@@ -12,13 +12,14 @@ from tamcmc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("pipeline", ["0", "1"], ids=["one-batch", "two-halves-in-flight"])
+@pytest.mark.parametrize("pipeline", ["0", "2", "3"], ids=["one-batch", "two-parts-in-flight", "three-parts-in-flight"])
 def test_hip_and_oracle_drive_identical_chains(accel_mod, orc, monkeypatch, pipeline):
-    """pipeline = 1: the opt-in loop that keeps the chains' two halves in flight as separate sub-batches and handles one
-    half on the host while the GPU evaluates the other (tamcmc_sampler.cpp: pipelined_iteration) -- same draws, same
-    decisions as the one-batch loop and as the oracle-driven sampler."""
+    """pipeline = 2 / 3: the opt-in loop that keeps the chains in flight as 2 / 3 separate sub-batches and handles one
+    part on the host while the GPU evaluates the others, with the draws on a thread of their own (tamcmc_sampler.cpp:
+    pipelined_iteration) -- same draws, same decisions as the one-batch loop and as the oracle-driven sampler (12 chains,
+    swap attempts every second iteration: pairs inside a part, across two parts, re-proposals after swaps)."""
     monkeypatch.setenv("TAMCMC_SAMPLER_PIPELINE", pipeline)
-    nch, nit = 8, 400
+    nch, nit = 12, 400
     w, sw, pp, b = tps.ms_global_prior_setup()
     w = dict(w); w["x"] = synth.grid(6000, 2300.0, 840.0 / 6000)
     m, _ = orc.model(3, w["params_true"], w["plength"], w["x"])
