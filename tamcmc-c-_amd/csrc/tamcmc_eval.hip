@@ -45,13 +45,8 @@
 
 #include "tamcmc_eval_body.h"
 
-#ifdef TM_NUM_SGPR     // experiment: cap the scalar registers (residency of 256-thread workgroups: <= 96 -> 7 per CU, <= 80 -> 8)
-#define TM_SGPR_ATTR __attribute__((amdgpu_num_sgpr(TM_NUM_SGPR)))
-#else
-#define TM_SGPR_ATTR
-#endif
 template <bool GRAD, bool GEN>
-__global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) TM_SGPR_ATTR void tamcmc_eval_kernel(TmEvalArgs a)
+__global__ __launch_bounds__(TM_THREADS, (GRAD ? TM_LB_GRAD : TM_LB_FWD)) void tamcmc_eval_kernel(TmEvalArgs a)
 {
     TM_STAMP(0);
     // Workgroups go to the 8 XCDs round-robin by linear id.  Default (order_mode 2): x = chain, y = launch rank, so
