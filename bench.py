@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--no-ensemble", action="store_true", help="skip the C5 ensemble leg")
     ap.add_argument("--ensemble-stars", type=int, default=32, help="stars of the ensemble leg (BASELINE C5: 32), spread over the ranks")
+    ap.add_argument("--strict-exit", action="store_true", help="exit with code 3 (after printing the line) when the sharded sampler leg hit its deadline; "
+                    "by default the line carries the error and the exit code stays 0, so that a stuck exchange cannot cost the measurement")
     ap.add_argument("--sharded-seconds", type=float, default=150.0, help="deadline of the sharded sampler leg (a hung exchange must not cost the line)")
     return ap.parse_args(argv)
 
@@ -359,7 +361,7 @@ def run_rank(args):
     if not args.no_sampler:
         def bail():
             emit(f"the sharded sampler leg did not finish within {args.sharded_seconds:.0f} s")
-            os._exit(0)
+            os._exit(3 if args.strict_exit else 0)
         dog = threading.Timer(args.sharded_seconds, bail)
         dog.daemon = True
         dog.start()
