@@ -15,6 +15,9 @@
  *       three reference values recorded in SURVEY.md App. D (tests/test_oracle.py).
  *   Everything else is checked through properties (window truncation limits, linearity in heights,
  *   agreement of independent code paths) -- see tests/.
+ *   The gradient (orc_grad_analytic, end of this file) has no reference counterpart at all (MALA.cpp:18,317-333):
+ *   it restates SURVEY.md App. D and is pinned, entry by entry, against finite differences of THIS file's
+ *   log-likelihood (tests/test_oracle_grad.py) -- "parity unpinned" with respect to the reference by construction.
  *
  * Arithmetic notes (all fp64 like the reference):
  *   - Build with -ffp-contract=off: the reference is built with plain -O3 (CMakeLists.txt:13-36),
