@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import gradcheck
 from tamcmc_amd import sampler as S
 from tamcmc_amd.setup_io import Setup, model_file_slices
 
@@ -42,6 +43,12 @@ def check_against_oracle(accel_mod, orc, s, P, T, grad=True):
         if grad:
             logL2, st2, g = acc.eval_batch(P, T, grad=True)
             assert np.allclose(logL2, logL, rtol=1e-13) and np.all(np.isfinite(g)) and g.shape == (len(P), s.Nvars)
+            # every gradient entry against the oracle's analytic gradient (tolerance: tests/gradcheck.py), whatever the
+            # file's truncation constant
+            ref, ref_abs, _, gst = orc.grad_analytic(s.model_case, s.plength, s.x, s.y, P, T, s.index_to_relax,
+                                                     likelihood_p=s.likelihood_p)
+            assert np.all(gst == 0)
+            gradcheck.assert_grad_entrywise(g, ref, ref_abs, tag=f"model {s.model_case}, {s.Nx} bins")
     return logL
 
 
