@@ -53,6 +53,12 @@ def run_phase_sharded(setup, evaluator, dist, rank, world, seed, device=None, re
                     setup.priors, setup.extra_priors)
     it0 = O.restore_apply(setup, smp)
     smp.init()
+    if world > 1:
+        # With the NCCL (= RCCL) backend the first call on a group has to involve every rank; the boundary exchange
+        # involves two (torch.distributed.batch_isend_irecv's note).  One all-rank reduction opens the communicator.
+        import torch
+        t0 = torch.zeros(1, dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t0)
     nv = smp.Nvars
     Nsamples, Nbuffer = int(setup.get("Outputs", "Nsamples")), int(setup.get("Outputs", "Nbuffer"))
     out = C.c_void_p()
