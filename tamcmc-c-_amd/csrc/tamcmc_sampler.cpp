@@ -536,6 +536,14 @@ struct tamcmc_sampler {
     // of two, chain m's rows still in its core's cache).  A parallel-tempering swap, which comes in between
     // (MALA.cpp:676), re-proposes the two chains it touched; setters of restored state drop the flag.
     bool proposed_ahead = false;                 // v_prop / p_prop already hold the proposals of the coming mh_step
+    // While the proposal matrix of a chain is frozen (Acquire phase, or between two adaptation periods) its step
+    // chol(...) z depends on no outcome either: it is computed with the draws, under the GPU evaluation, and the accept
+    // pass only adds it to whichever state the chain ends up in (same sum, same order: propose_chain).  A step is used
+    // only if it was made from the normals and the factor that are current (generation counters, so that no path that
+    // redraws or refactors can leave a stale step behind).
+    std::vector<double> step;                    // [nloc][Nvars]
+    std::vector<uint64_t> step_zgen, step_cgen, chol_gen;   // per chain: generations the step was made from; factor generation
+    uint64_t z_gen = 1;                          // bumped whenever z_all is rewritten
     // Pipelined loop (tamcmc_sampler_run / _run_sharded with the HIP evaluator): the local chains in two halves, each its
     // own sub-batch on its own stream (tamcmc_eval_batch_begin_part).  One half's accept step, next proposals and next
     // launch happen on the host while the GPU evaluates the other half -- chains are independent inside an iteration
@@ -616,6 +624,7 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
     s->u_mh.resize(n); s->z.resize(nv); s->status.resize(n);
     s->plans.resize((size_t)n + 1);
     s->z_all.resize((size_t)n * nv); s->chol_scratch.resize((size_t)n * (2 * (size_t)nv * nv + nv));
+    s->step.assign((size_t)n * nv, 0.0); s->step_zgen.assign(n, 0); s->step_cgen.assign(n, 0); s->chol_gen.assign(n, 1);
     {   // host threads for the per-chain work: TAMCMC_SAMPLER_THREADS, default min(cores, 16, chains), and no more than
         // the work of an iteration pays for: a fork costs a few microseconds, a chain's proposal ~nv^2 flops (measured:
         // 10 chains x 9 variables run 25 % faster on one thread than on ten; 64 x 44 want all sixteen)
@@ -809,6 +818,23 @@ static void draw_pt(tamcmc_sampler *s)
 
 extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s);
 
+// The step chol(...) z of local chain m from the normals in z_all, ahead of its use (only with a factor in hand: the
+// matrix may be about to change, and a factorisation here could report a failure that never happens).
+static inline void step_chain(tamcmc_sampler *s, int m)
+{
+    if (!s->chol_valid[m]) return;
+    const int nv = s->Nvars;
+    const double *z = &s->z_all[(size_t)m * nv];
+    const double *Lc = &s->Lchol[(size_t)m * nv * nv];
+    double *st = &s->step[(size_t)m * nv];
+    for (int a = 0; a < nv; a++) {
+        double acc = 0.0;
+        for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * z[b];
+        st[a] = acc;
+    }
+    s->step_zgen[m] = s->z_gen; s->step_cgen[m] = s->chol_gen[m];
+}
+
 // Proposal of local chain m from its current vars and the normals in z_all: v' = v + chol((Sigma + eps2 I) sigma) z
 // (MALA.cpp:335-353), the factor recomputed only when the proposal parameters changed.  Returns false when the matrix
 // was not positive definite.
@@ -824,13 +850,19 @@ static bool propose_chain(tamcmc_sampler *s, int m, bool with_prior = false)
                 tmp[(size_t)a * nv + b] = (C[(size_t)a * nv + b] + (a == b ? s->cfg.epsilon2 : 0.0)) * s->sigma[m];   // :342
         ok = cholesky(tmp, nv, &s->Lchol[(size_t)m * nv * nv], tmp + (size_t)nv * nv);
         s->chol_valid[m] = 1;
+        s->chol_gen[m]++;
     }
-    const double *z = &s->z_all[(size_t)m * nv];
-    const double *Lc = &s->Lchol[(size_t)m * nv * nv];
-    for (int a = 0; a < nv; a++) {
-        double acc = 0.0;
-        for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * z[b];
-        s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + acc;             // :349
+    if (s->step_zgen[m] == s->z_gen && s->step_cgen[m] == s->chol_gen[m]) {
+        const double *st = &s->step[(size_t)m * nv];                                    // made ahead by step_chain
+        for (int a = 0; a < nv; a++) s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + st[a];
+    } else {
+        const double *z = &s->z_all[(size_t)m * nv];
+        const double *Lc = &s->Lchol[(size_t)m * nv * nv];
+        for (int a = 0; a < nv; a++) {
+            double acc = 0.0;
+            for (int b = 0; b <= a; b++) acc += Lc[(size_t)a * nv + b] * z[b];
+            s->v_prop[(size_t)m * nv + a] = s->vars[(size_t)m * nv + a] + acc;         // :349
+        }
     }
     std::memcpy(&s->p_prop[(size_t)m * np], &s->params[(size_t)m * np], sizeof(double) * np);
     for (int k = 0; k < nv; k++) s->p_prop[(size_t)m * np + s->index_to_relax[k]] = s->v_prop[(size_t)m * nv + k];
@@ -920,7 +952,7 @@ static void draw_collect(tamcmc_sampler *s)
     while (s->draw_done.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
     s->draw_pending = false;
     std::swap(s->u_mh, s->packet.u_mh);
-    std::swap(s->z_all, s->packet.z_all);
+    std::swap(s->z_all, s->packet.z_all); s->z_gen++;
     if (s->packet.has_pt) { s->pt_u = s->packet.pt_u; s->pt_A = s->packet.pt_A; s->pt_cached = true; }
 }
 
@@ -965,7 +997,7 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
         if (!s->reserved) { rc = tamcmc_ctx_reserve(s->hip_ctx, n); if (rc != TAMCMC_OK) return rc; s->reserved = true; }
         if (!s->drawn_ahead) {
             draw_mh(s);
-            s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+            s->z_gen++; s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
         }
         s->drawn_ahead = false;
         if (!s->proposed_ahead)
@@ -996,7 +1028,7 @@ static int pipelined_iteration(tamcmc_sampler *s, bool launch_next, uint8_t *mov
     } else {
         if (due && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
         draw_mh(s);
-        s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+        s->z_gen++; s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
     }
     s->drawn_ahead = true;
     if (launch_next) {
@@ -1084,7 +1116,7 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     double t0 = now(), t1;
     if (!s->drawn_ahead) {
         draw_mh(s);
-        s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+        s->z_gen++; s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
     }
     s->drawn_ahead = false;
     std::atomic<int64_t> bad{0};
@@ -1112,7 +1144,13 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         t1 = now(); s->t_phase[2] += t1 - t0; t0 = t1;
         if (tamcmc_sampler_pt_due(s) && !s->pt_cached) { draw_pt(s); s->pt_cached = true; }
         draw_mh(s);
-        s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); });
+        {
+            // (the accept step of THIS iteration adapts the proposal: its factor is about to change, no step ahead)
+            int64_t per_ = 1;
+            const bool steps_ahead = !(learning_now(s, i, &per_) && (i % per_) == 0);
+            s->z_gen++;
+            s->pool->run(n, [&](int m) { s->plans[m].fill(&s->z_all[(size_t)m * nv]); if (steps_ahead) step_chain(s, m); });
+        }
         s->drawn_ahead = true;
         t1 = now(); s->t_phase[3] += t1 - t0; t0 = t1;
         rc = tamcmc_eval_batch_end(s->hip_ctx, n, s->L_prop.data(), s->status.data());
