@@ -166,6 +166,10 @@ void tamcmc_glibc_rand(uint32_t seed, int32_t n, int32_t *out);
 /* the same after `skip` values were passed over by the generator's jump-ahead (a sharded sampler jumps over the draws of
  * the chains other processes own): must equal tamcmc_glibc_rand's values skip .. skip + n - 1 (test hook) */
 void tamcmc_glibc_rand_jump(uint32_t seed, uint64_t skip, int32_t n, int32_t *out);
+/* the sampler's lower Cholesky factor of a row-major n x n matrix (MALA.cpp:344, tmpmat.llt().matrixL()): L row-major,
+ * zeros above the diagonal; returns 0, or 1 when a pivot is not positive (the columns before it are filled in) -- test
+ * hook: the blocked form must be the textbook factor bit for bit */
+int tamcmc_host_cholesky(const double *A, int32_t n, double *L);
 
 #ifdef __cplusplus
 }

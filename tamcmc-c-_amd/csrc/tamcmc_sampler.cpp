@@ -388,26 +388,58 @@ struct Rng {
 };
 
 // lower Cholesky factor of an n x n SPD matrix (what tmpmat.llt().matrixL() returns, MALA.cpp:344).
-// Right-looking form: every element still receives a_ij - l_i0 l_j0 - l_i1 l_j1 - ... in that order (the same
-// operations, in the same order, as the textbook left-looking loops), but the inner loop is a contiguous
-// elementwise update the compiler can vectorise without reassociating anything.
-__attribute__((target_clones("avx2", "default")))
-bool cholesky(const double *A, int n, double *L, double *W /* n*n + n scratch */)
+// Right-looking form, four columns per pass over the trailing matrix: every element still receives
+// a_ij - l_i0 l_j0 - l_i1 l_j1 - ... in that order, each term a separate multiply and subtract (the same operations, in
+// the same order, as the textbook left-looking loops -- bitwise the same factor, and the same columns filled in when
+// the matrix turns out not to be positive definite), but the inner loops are contiguous elementwise updates the
+// compiler vectorises without reassociating anything, and a pass over the trailing matrix applies four columns (64
+// factorisations of 44 x 44 per iteration are the longest item of the adapting phase's accept step).
+static inline bool chol_col(double *__restrict__ W, double *__restrict__ L, double *__restrict__ c, int n, int col)
 {
-    double *col = W + (size_t)n * n;
+    const double d = W[(size_t)col * n + col];
+    if (!(d > 0.0)) return false;
+    const double l = std::sqrt(d);
+    L[(size_t)col * n + col] = l;
+    for (int i = col + 1; i < n; i++) { c[i] = W[(size_t)i * n + col] / l; L[(size_t)i * n + col] = c[i]; }
+    return true;
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default")))
+bool cholesky(const double *A, int n, double *L, double *W /* n*n + 4*n scratch */)
+{
+    double *__restrict__ c0 = W + (size_t)n * n, *__restrict__ c1 = c0 + n, *__restrict__ c2 = c1 + n, *__restrict__ c3 = c2 + n;
     std::memset(L, 0, sizeof(double) * (size_t)n * n);
     for (int i = 0; i < n; i++)
         for (int j = 0; j <= i; j++) W[(size_t)i * n + j] = A[(size_t)i * n + j];
-    for (int k = 0; k < n; k++) {
-        const double d = W[(size_t)k * n + k];
-        if (!(d > 0.0)) return false;
-        const double lkk = std::sqrt(d);
-        L[(size_t)k * n + k] = lkk;
-        for (int i = k + 1; i < n; i++) { col[i] = W[(size_t)i * n + k] / lkk; L[(size_t)i * n + k] = col[i]; }
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        if (!chol_col(W, L, c0, n, k)) return false;
+        { const double q0 = c0[k + 1];
+          for (int i = k + 1; i < n; i++) W[(size_t)i * n + k + 1] -= c0[i] * q0; }
+        if (!chol_col(W, L, c1, n, k + 1)) return false;
+        { const double q0 = c0[k + 2], q1 = c1[k + 2];
+          for (int i = k + 2; i < n; i++) { const double t = W[(size_t)i * n + k + 2] - c0[i] * q0; W[(size_t)i * n + k + 2] = t - c1[i] * q1; } }
+        if (!chol_col(W, L, c2, n, k + 2)) return false;
+        { const double q0 = c0[k + 3], q1 = c1[k + 3], q2 = c2[k + 3];
+          for (int i = k + 3; i < n; i++) { double t = W[(size_t)i * n + k + 3] - c0[i] * q0; t = t - c1[i] * q1; W[(size_t)i * n + k + 3] = t - c2[i] * q2; } }
+        if (!chol_col(W, L, c3, n, k + 3)) return false;
+        for (int i = k + 4; i < n; i++) {
+            const double a0 = c0[i], a1 = c1[i], a2 = c2[i], a3 = c3[i];
+            double *__restrict__ w = W + (size_t)i * n;
+            for (int j = k + 4; j <= i; j++) {
+                double t = w[j] - a0 * c0[j];
+                t = t - a1 * c1[j];
+                t = t - a2 * c2[j];
+                w[j] = t - a3 * c3[j];
+            }
+        }
+    }
+    for (; k < n; k++) {
+        if (!chol_col(W, L, c0, n, k)) return false;
         for (int i = k + 1; i < n; i++) {
-            const double li = col[i];
-            double *w = W + (size_t)i * n;
-            for (int j = k + 1; j <= i; j++) w[j] -= li * col[j];
+            const double li = c0[i];
+            double *__restrict__ w = W + (size_t)i * n;
+            for (int j = k + 1; j <= i; j++) w[j] -= li * c0[j];
         }
     }
     return true;
@@ -623,7 +655,7 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
     s->p_prop.resize((size_t)n * Nparams); s->v_prop.resize((size_t)n * nv); s->L_prop.resize(n); s->lpr_prop.resize(n); s->perr_prop.resize(n);
     s->u_mh.resize(n); s->z.resize(nv); s->status.resize(n);
     s->plans.resize((size_t)n + 1);
-    s->z_all.resize((size_t)n * nv); s->chol_scratch.resize((size_t)n * (2 * (size_t)nv * nv + nv));
+    s->z_all.resize((size_t)n * nv); s->chol_scratch.resize((size_t)n * (2 * (size_t)nv * nv + 4 * (size_t)nv));
     s->step.assign((size_t)n * nv, 0.0); s->step_zgen.assign(n, 0); s->step_cgen.assign(n, 0); s->chol_gen.assign(n, 1);
     {   // host threads for the per-chain work: TAMCMC_SAMPLER_THREADS, default min(cores, 16, chains), and no more than
         // the work of an iteration pays for: a fork costs a few microseconds, a chain's proposal ~nv^2 flops (measured:
@@ -733,15 +765,30 @@ static void update_proposal(tamcmc_sampler *s, int m, double gamma, double accep
     for (int k = 0; k < nv; k++) { mu[k] = mu[k] + gamma * (v[k] - mu[k]); nrm += mu[k] * mu[k]; }
     nrm = std::sqrt(nrm);
     if (!(nrm <= A1)) for (int k = 0; k < nv; k++) mu[k] = mu[k] * A1 / nrm;
-    // Sigma <- p2(Sigma + gamma ((v - mu)(v - mu)^T - Sigma)), with the ALREADY updated mu
-    double fn = 0.0;
-    for (int i = 0; i < nv; i++)
-        for (int j = 0; j < nv; j++) {
-            const double mat = (v[i] - mu[i]) * (v[j] - mu[j]);
-            double &c = C[(size_t)i * nv + j];
-            c = c + gamma * (mat - c);
-            fn += c * c;
+    // Sigma <- p2(Sigma + gamma ((v - mu)(v - mu)^T - Sigma)), with the ALREADY updated mu.  The Frobenius norm of p2 is
+    // only ever compared with A1 (1e14 by default) and is summed here in four interleaved parts -- the reference takes
+    // Eigen's .norm(), whose order of summation is Eigen's own; one running sum was a chain of nv^2 dependent additions
+    // (2 us per chain at 44 variables) in front of every factorisation.
+    double *dv = &s->chol_scratch[(size_t)m * (2 * (size_t)nv * nv + 4 * (size_t)nv)];      // (free between factorisations)
+    for (int k = 0; k < nv; k++) dv[k] = v[k] - mu[k];
+    double f4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < nv; i++) {
+        const double di = dv[i];
+        double *__restrict__ c = C + (size_t)i * nv;
+        int j = 0;
+        for (; j + 4 <= nv; j += 4)
+            for (int q = 0; q < 4; q++) {
+                const double cn = c[j + q] + gamma * (di * dv[j + q] - c[j + q]);
+                c[j + q] = cn;
+                f4[q] += cn * cn;
+            }
+        for (; j < nv; j++) {
+            const double cn = c[j] + gamma * (di * dv[j] - c[j]);
+            c[j] = cn;
+            f4[0] += cn * cn;
         }
+    }
+    double fn = (f4[0] + f4[1]) + (f4[2] + f4[3]);
     fn = std::sqrt(fn);
     if (!(fn <= A1)) for (size_t e = 0; e < (size_t)nv * nv; e++) C[e] = C[e] * A1 / fn;
     // sigma <- p1(sigma + gamma (acceptance - target))
@@ -818,6 +865,13 @@ static void draw_pt(tamcmc_sampler *s)
 
 extern "C" int tamcmc_sampler_pt_due(const tamcmc_sampler *s);
 
+extern "C" int tamcmc_host_cholesky(const double *A, int32_t n, double *L)
+{
+    if (!A || !L || n < 1) return TAMCMC_E_INVALID;
+    std::vector<double> W((size_t)n * n + 4 * (size_t)n);
+    return cholesky(A, n, L, W.data()) ? 0 : 1;
+}
+
 // The step chol(...) z of local chain m from the normals in z_all, ahead of its use (only with a factor in hand: the
 // matrix may be about to change, and a factorisation here could report a failure that never happens).
 static inline void step_chain(tamcmc_sampler *s, int m)
@@ -843,7 +897,7 @@ static bool propose_chain(tamcmc_sampler *s, int m, bool with_prior = false)
     const int nv = s->Nvars, np = s->Nparams;
     bool ok = true;
     if (!s->chol_valid[m]) {
-        double *tmp = &s->chol_scratch[(size_t)m * (2 * (size_t)nv * nv + nv)];
+        double *tmp = &s->chol_scratch[(size_t)m * (2 * (size_t)nv * nv + 4 * (size_t)nv)];
         const double *C = &s->covar[(size_t)m * nv * nv];
         for (int a = 0; a < nv; a++)
             for (int b = 0; b < nv; b++)
