@@ -61,6 +61,7 @@ typedef struct tamcmc_ctx tamcmc_ctx;
 #define TAMCMC_E_NOMEM             6
 #define TAMCMC_E_NOVARS            7  /* gradient requested before tamcmc_ctx_set_vars                        */
 #define TAMCMC_E_NOGRAD            8  /* gradient not available for this model/likelihood id                  */
+#define TAMCMC_PENDING            -1  /* tamcmc_eval_batch_poll only: not an error, the chain's result has not arrived yet */
 
 /* per-chain status written by the eval calls */
 #define TAMCMC_CHAIN_OK            0
@@ -133,6 +134,25 @@ int tamcmc_eval_batch_begin(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams, c
 int tamcmc_eval_batch_end(tamcmc_ctx *ctx, int32_t Nchains, double *logL, int32_t *status);
 
 #define TAMCMC_MAX_PARTS 4
+/* Armed batch -- for a host loop whose next parameters depend on the results of the batch in flight (a sampler):
+ * _arm puts the launches of the NEXT likelihood-only batch into the stream behind a one-wave gate kernel, while the
+ * current batch is still being evaluated (allowed between _begin / _fire and _end of a batch of the same size; the
+ * buffers must already be sized: tamcmc_ctx_reserve or an earlier batch), so that the launch calls cost nothing on the
+ * critical path; _fire copies the parameters into the pinned input buffer and opens the gate with one store -- it takes
+ * the place of _begin, and _end collects the results as usual.  While a batch is armed every other entry point of the
+ * context returns TAMCMC_E_INVALID except _fire, _end (of the batch in flight), _disarm and tamcmc_ctx_destroy.  _disarm
+ * opens the gate of a batch that will not be fired (it runs on the previous parameters, is waited for, and nothing is
+ * handed out).  The gate itself gives up after ~2 s: a wave never outlives a host that died before firing. */
+int tamcmc_eval_batch_arm(tamcmc_ctx *ctx, int32_t Nchains);
+/* One chain of the batch in flight (_begin / _fire, not yet _end): TAMCMC_OK with its logL and status once they have
+ * arrived, TAMCMC_PENDING before.  Results arrive chain by chain (each is finalized by the last of its tiles), so a host
+ * loop can start on a chain's accept step while the others are still being evaluated.  Read-only: any number of threads
+ * may poll (different or the same chains) while no other entry point of the context is called; _end is still due, and
+ * is the call that reports a failed launch -- a poller must bound its patience and then go there. */
+int tamcmc_eval_batch_poll(const tamcmc_ctx *ctx, int32_t chain, double *logL, int32_t *status);
+int tamcmc_eval_batch_fire(tamcmc_ctx *ctx, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs);
+int tamcmc_eval_batch_disarm(tamcmc_ctx *ctx);
+
 /* The same in up to TAMCMC_MAX_PARTS PARTS that may be in flight together (part = 0 .. 3; every part but 0 runs on a stream
  * of its own): chains
  * [first, first + Nchains) of the context's numbering -- the ranges of parts in flight must not overlap; with several

@@ -26,7 +26,11 @@
  * Environment switches read by tamcmc_sampler_create*: TAMCMC_SAMPLER_THREADS (host threads of the per-chain fork-join
  * pool), TAMCMC_SAMPLER_TIMING=1 (phase times printed at destroy), TAMCMC_SAMPLER_PIPELINE=2 (HIP evaluator, loops in the
  * library: the local chains as two sub-batches in flight, one handled on the host while the GPU evaluates the other;
- * same draws and decisions; off by default, measured slower at 64 chains x 1e5 bins).
+ * same draws and decisions; off by default, measured slower at 64 chains x 1e5 bins), TAMCMC_SAMPLER_ARM=0 (HIP evaluator:
+ * do NOT put the next iteration's launches into the stream ahead of its parameters -- tamcmc_eval_batch_arm / _fire, on by
+ * default inside tamcmc_sampler_run / _run_sharded), TAMCMC_SAMPLER_ARRIVE=0 (HIP evaluator: wait for the whole batch
+ * before the accept pass instead of running a chain's accept step when its own result has arrived --
+ * tamcmc_eval_batch_poll, on by default).  None of them changes a draw or a decision.
  */
 #ifndef TAMCMC_SAMPLER_H
 #define TAMCMC_SAMPLER_H

@@ -21,6 +21,7 @@ EXPORTS = [
     "tamcmc_eval_batch", "tamcmc_eval_batch_device",
     "tamcmc_eval_batch_begin", "tamcmc_eval_batch_end",
     "tamcmc_ctx_reserve", "tamcmc_eval_batch_begin_part", "tamcmc_eval_batch_end_part",
+    "tamcmc_eval_batch_arm", "tamcmc_eval_batch_fire", "tamcmc_eval_batch_disarm", "tamcmc_eval_batch_poll",
     "tamcmc_model_explicit", "tamcmc_ctx_set_stream", "tamcmc_ctx_synchronize", "tamcmc_ctx_profile",
     "tamcmc_ctx_kernel_time", "tamcmc_ctx_clock_probe_begin", "tamcmc_ctx_clock_probe_end", "tamcmc_ctx_geometry", "tamcmc_ctx_destroy", "tamcmc_device_count",
     "tamcmc_strerror", "tamcmc_last_hip_error", "tamcmc_version",
@@ -203,6 +204,46 @@ class Accel:
         self._check(self._lib.tamcmc_eval_batch_end_part(self._ctx, int(part), _dptr(logL), st.ctypes.data_as(C.POINTER(C.c_int32))),
                     "tamcmc_eval_batch_end_part")
         return logL, st
+
+    def begin(self, params, Tcoefs):
+        """Likelihood evaluation of a batch, launched and not waited for (end() collects it)."""
+        params = _c64(params)
+        if params.ndim != 2 or params.shape[1] != self.Nparams:
+            raise ValueError(f"expected (n, {self.Nparams}) params, got {params.shape}")
+        T = _c64(Tcoefs, (params.shape[0],))
+        self._check(self._lib.tamcmc_eval_batch_begin(self._ctx, params.shape[0], self.Nparams, _dptr(params), _dptr(T)), "tamcmc_eval_batch_begin")
+        self._n_flight = params.shape[0]
+
+    def end(self):
+        n = self._n_flight
+        logL = np.empty(n)
+        st = np.empty(n, dtype=np.int32)
+        self._check(self._lib.tamcmc_eval_batch_end(self._ctx, n, _dptr(logL), st.ctypes.data_as(C.POINTER(C.c_int32))), "tamcmc_eval_batch_end")
+        return logL, st
+
+    def poll(self, chain):
+        """(logL, status) of one chain of the batch in flight, or None while it has not arrived."""
+        L, st = C.c_double(), C.c_int32()
+        rc = self._lib.tamcmc_eval_batch_poll(self._ctx, int(chain), C.byref(L), C.byref(st))
+        if rc == -1:
+            return None
+        self._check(rc, "tamcmc_eval_batch_poll")
+        return L.value, st.value
+
+    def arm(self, nchains):
+        """The launches of the next likelihood batch go into the stream now, behind a gate; fire() supplies the parameters."""
+        self._check(self._lib.tamcmc_eval_batch_arm(self._ctx, int(nchains)), "tamcmc_eval_batch_arm")
+
+    def fire(self, params, Tcoefs):
+        params = _c64(params)
+        if params.ndim != 2 or params.shape[1] != self.Nparams:
+            raise ValueError(f"expected (n, {self.Nparams}) params, got {params.shape}")
+        T = _c64(Tcoefs, (params.shape[0],))
+        self._check(self._lib.tamcmc_eval_batch_fire(self._ctx, params.shape[0], self.Nparams, _dptr(params), _dptr(T)), "tamcmc_eval_batch_fire")
+        self._n_flight = params.shape[0]
+
+    def disarm(self):
+        self._check(self._lib.tamcmc_eval_batch_disarm(self._ctx), "tamcmc_eval_batch_disarm")
 
     def eval_batch_device(self, nchains, d_params, d_T, d_logL, d_grad=0, d_status=0):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); enqueued on the ctx stream, no sync."""

@@ -77,13 +77,17 @@ struct tamcmc_ctx {
     hipEvent_t ev_done = nullptr;  // completion of a host-pointer call, polled (see wait_done)
     bool ev_recorded = false;      // wait_data: the event of the current call has been recorded (lazily)
     int in_flight = 0;             // chains of a tamcmc_eval_batch_begin not yet collected by _end
+    int armed = 0;                 // chains of a tamcmc_eval_batch_arm whose launches wait behind the gate for _fire
+    uint32_t *h_gate = nullptr, *dv_gate = nullptr;   // pinned word the gate kernel watches
+    uint32_t gate_seq = 0;         // value that opens the gate of the armed batch
     // tamcmc_eval_batch_begin_part / _end_part: two sub-batches of the context's chains in flight at once, part 1 on a
     // stream of its own; a part's rows of every per-chain buffer start at its first chain
     hipStream_t part_streams[TAMCMC_MAX_PARTS] = {};      // [0] unused (part 0 runs on the context stream), created on demand
     int part_first[TAMCMC_MAX_PARTS] = {}, part_n[TAMCMC_MAX_PARTS] = {};
     bool part_ev_recorded[TAMCMC_MAX_PARTS] = {};
     hipEvent_t part_ev[TAMCMC_MAX_PARTS] = {};
-    bool parts_busy() const { for (int n : part_n) if (n) return true; return false; }
+    // (an armed batch counts: nothing but _fire / _disarm / _end may touch the context while launches wait behind a gate)
+    bool parts_busy() const { if (armed) return true; for (int n : part_n) if (n) return true; return false; }
     // variables
     int Nvars = 0;
     int32_t *d_relax = nullptr;
@@ -377,8 +381,10 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
 {
     if (!c) return TAMCMC_OK;
     (void)hipSetDevice(c->device);
+    if (c->armed && c->h_gate) { __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE); c->armed = 0; }   // let the gate go
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_batch(c);
+    (void)hipHostFree(c->h_gate);
     (void)hipFree(c->d_x2); (void)hipFree(c->d_y); (void)hipFree(c->d_lx); (void)hipFree(c->d_isig2); (void)hipFree(c->d_spec);
     (void)hipFree(c->d_model); (void)hipFree(c->d_relax);
     (void)hipHostFree(c->h_in); (void)hipHostFree(c->h_out); (void)hipHostFree(c->h_status);
@@ -767,7 +773,7 @@ static int ensure_staging(tamcmc_ctx *c, int Nchains)
 
 extern "C" int tamcmc_eval_batch_begin(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs)
 {
-    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight || c->parts_busy()) return TAMCMC_E_INVALID;
+    if (!c || Nchains < 1 || !params || !Tcoefs || Nparams != c->L.Nparams || c->in_flight || c->armed || c->parts_busy()) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, false);
     if (rc != TAMCMC_OK) return rc;
@@ -797,9 +803,84 @@ extern "C" int tamcmc_eval_batch_end(tamcmc_ctx *c, int32_t Nchains, double *log
     return TAMCMC_OK;
 }
 
+extern "C" int tamcmc_eval_batch_poll(const tamcmc_ctx *c, int32_t chain, double *logL, int32_t *status)
+{
+    if (!c || !logL || !status || chain < 0 || chain >= c->in_flight) return TAMCMC_E_INVALID;
+    const uint64_t v = reinterpret_cast<volatile const uint64_t *>(c->h_out)[chain];
+    const int32_t st = reinterpret_cast<volatile const int32_t *>(c->h_status)[chain];
+    if (v == TM_PENDING_BITS || st == -1) return TAMCMC_PENDING;
+    std::memcpy(logL, &v, sizeof(double));
+    *status = st;
+    return TAMCMC_OK;
+}
+
+int tm_launch_gate(const uint32_t *dv_gate, uint32_t target, void *stream);      // tamcmc_setup.hip
+
+// An armed batch: its launches are put into the stream AHEAD of its parameters, behind a one-wave gate kernel that
+// watches a pinned word.  A host loop arms batch i+1 while the GPU evaluates batch i (the launch calls, ~6 us, are then
+// hidden under that evaluation) and fires it with one store once the parameters are known.
+extern "C" int tamcmc_eval_batch_arm(tamcmc_ctx *c, int32_t Nchains)
+{
+    if (!c || Nchains < 1 || c->armed || c->parts_busy()) return TAMCMC_E_INVALID;
+    if (c->in_flight && c->in_flight != Nchains) return TAMCMC_E_INVALID;
+    // never (re)allocate under a batch in flight: tamcmc_ctx_reserve (or an earlier batch of this size) sized the buffers
+    if (Nchains > c->cap || Nchains > c->h_cap || c->h_nvars != c->Nvars) {
+        if (c->in_flight) return TAMCMC_E_INVALID;
+        const int rc = tamcmc_ctx_reserve(c, Nchains);
+        if (rc != TAMCMC_OK) return rc;
+    }
+    TM_HIP(hipSetDevice(c->device));
+    if (!c->h_gate) {
+        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_gate), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dv_gate), c->h_gate, 0));
+        *c->h_gate = c->gate_seq;
+    }
+    const uint32_t target = c->gate_seq + 1;
+    int rc = tm_launch_gate(c->dv_gate, target, c->stream);
+    if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "gate launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
+    const size_t n = (size_t)Nchains;
+    rc = enqueue(c, Nchains, c->dv_in, c->dv_in + n * c->L.Nparams, c->dv_out, nullptr, c->dv_status, nullptr, nullptr);
+    c->gate_seq = target;
+    if (rc != TAMCMC_OK) {            // the gate is in the stream: open it, nothing sits behind it
+        __atomic_store_n(c->h_gate, target, __ATOMIC_RELEASE);
+        return rc;
+    }
+    c->armed = Nchains;
+    return TAMCMC_OK;
+}
+
+extern "C" int tamcmc_eval_batch_fire(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs)
+{
+    if (!c || !params || !Tcoefs || Nparams != c->L.Nparams || c->armed != Nchains || Nchains < 1 || c->in_flight) return TAMCMC_E_INVALID;
+    const size_t n = (size_t)Nchains;
+    std::memcpy(c->h_in, params, n * Nparams * sizeof(double));
+    std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
+    mark_pending(c, Nchains, (size_t)Nchains);
+    __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE);      // (after the parameters and the markers)
+    c->ev_recorded = false;
+    c->armed = 0;
+    c->in_flight = Nchains;
+    return TAMCMC_OK;
+}
+
+// Opens the gate of an armed batch that will not be fired (the loop ended, or failed): it runs on whatever the input
+// buffer holds -- the previous batch's parameters -- and is waited for here; nothing is handed out.
+extern "C" int tamcmc_eval_batch_disarm(tamcmc_ctx *c)
+{
+    if (!c) return TAMCMC_E_INVALID;
+    if (!c->armed) return TAMCMC_OK;
+    if (c->in_flight) return TAMCMC_E_INVALID;        // collect the batch in flight first (_end)
+    const int n = c->armed;
+    mark_pending(c, n, (size_t)n);
+    __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE);
+    c->ev_recorded = false;
+    c->armed = 0;
+    return wait_data(c, n, (size_t)n);
+}
+
 extern "C" int tamcmc_ctx_reserve(tamcmc_ctx *c, int32_t Nchains)
 {
-    if (!c || Nchains < 1 || c->in_flight || c->parts_busy()) return TAMCMC_E_INVALID;
+    if (!c || Nchains < 1 || c->in_flight || c->armed || c->parts_busy()) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     int rc = ensure_capacity(c, Nchains, false);
     if (rc != TAMCMC_OK) return rc;

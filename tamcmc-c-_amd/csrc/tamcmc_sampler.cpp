@@ -568,6 +568,16 @@ struct tamcmc_sampler {
     // of two, chain m's rows still in its core's cache).  A parallel-tempering swap, which comes in between
     // (MALA.cpp:676), re-proposes the two chains it touched; setters of restored state drop the flag.
     bool proposed_ahead = false;                 // v_prop / p_prop already hold the proposals of the coming mh_step
+    // The launches of the NEXT iteration's evaluation are put into the stream while the GPU works on this one
+    // (tamcmc_eval_batch_arm: they wait behind a gate kernel), so that between the accept step and the GPU starting on the
+    // new proposals there is one store instead of two kernel launches.  Only inside tamcmc_sampler_run / _run_sharded,
+    // which know that another iteration follows (arm_next); TAMCMC_SAMPLER_ARM=0 turns it off.
+    bool arm_enabled = true, arm_next = false, ctx_armed = false;
+    // Results arrive chain by chain (tamcmc_eval_batch_poll): the accept pass is forked BEFORE they are there, every
+    // participant watches the chains it owns and runs a chain's accept step the moment its logL has landed -- the fork
+    // and most of the pass are then under the evaluation's tail.  TAMCMC_SAMPLER_ARRIVE=0: wait for the whole batch first.
+    bool arrive_enabled = true;
+    std::vector<uint8_t> arrived;                // [nloc] accept step done on arrival (this iteration)
     // While the proposal matrix of a chain is frozen (Acquire phase, or between two adaptation periods) its step
     // chol(...) z depends on no outcome either: it is computed with the draws, under the GPU evaluation, and the accept
     // pass only adds it to whichever state the chain ends up in (same sum, same order: propose_chain).  A step is used
@@ -670,6 +680,9 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         if (nt < 1) nt = 1;
         s->pool.reset(new ChainPool(nt));
     { const char *e = getenv("TAMCMC_SAMPLER_TIMING"); s->timing = e && e[0] == '1'; }
+    { const char *e = getenv("TAMCMC_SAMPLER_ARM"); s->arm_enabled = !(e && e[0] == '0'); }
+    { const char *e = getenv("TAMCMC_SAMPLER_ARRIVE"); s->arrive_enabled = !(e && e[0] == '0'); }
+    s->arrived.assign((size_t)n, 0);
     {   // Two halves in flight (pipelined_iteration) with the draws on a thread of their own: OFF unless
         // TAMCMC_SAMPLER_PIPELINE=1.  Measured at 64 chains x 1e5 bins, PT every iteration (profiles/README.md, round 3):
         // without the draw thread the loop is host-bound and SLOWER (84 us per iteration against 65 us with one batch: four
@@ -715,7 +728,7 @@ extern "C" int tamcmc_sampler_destroy(tamcmc_sampler *s)
 {
     if (s && s->timing && s->t_iters > 0) {
         const double k = 1e6 / (double)s->t_iters;
-        fprintf(stderr, "[tamcmc sampler] %lld iterations; us per iteration: proposals %.1f, launch %.1f, priors %.1f, draw-ahead %.1f, wait %.1f, accept %.1f\n",
+        fprintf(stderr, "[tamcmc sampler] %lld iterations; us per iteration: proposals %.1f, launch %.1f, arm + priors %.1f, draw-ahead %.1f, wait %.1f, accept %.1f\n",
                 (long long)s->t_iters, s->t_phase[0] * k, s->t_phase[1] * k, s->t_phase[2] * k, s->t_phase[3] * k, s->t_phase[4] * k, s->t_phase[5] * k);
     }
     if (s && s->draw_thread.joinable()) {
@@ -1184,10 +1197,20 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     //    the parallel-tempering draws of THIS iteration (MALA.cpp:384,390; they come first in the stream), then the
     //    MH draws of the next one and their Box-Muller transforms.  u_mh of this iteration is kept aside first.
     int rc;
+    int perr_arrive = 0;
+    bool arrive_used = false;
     if (s->hip_ctx) {
-        rc = tamcmc_eval_batch_begin(s->hip_ctx, n, np, s->p_prop.data(), &s->T[off]);
+        if (s->ctx_armed) {
+            s->ctx_armed = false;
+            rc = tamcmc_eval_batch_fire(s->hip_ctx, n, np, s->p_prop.data(), &s->T[off]);
+        } else {
+            rc = tamcmc_eval_batch_begin(s->hip_ctx, n, np, s->p_prop.data(), &s->T[off]);
+        }
         if (rc != TAMCMC_OK) return rc;
         t1 = now(); s->t_phase[1] += t1 - t0; t0 = t1;
+        if (s->arm_next && s->arm_enabled) {       // the next iteration's launches, under this one's evaluation
+            s->ctx_armed = tamcmc_eval_batch_arm(s->hip_ctx, n) == TAMCMC_OK;      // (refused: the next step launches as usual)
+        }
         s->u_now = s->u_mh;
         // the priors of the proposals need nothing from the GPU: off the critical path
         s->pool->run(n, [&](int m) {
@@ -1207,6 +1230,32 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
         }
         s->drawn_ahead = true;
         t1 = now(); s->t_phase[3] += t1 - t0; t0 = t1;
+        int64_t period_a = 1;
+        const bool learn_a = learning_now(s, i, &period_a);
+        // Only where the accept step is long -- the iterations that adapt the proposal (covariance update and a
+        // factorisation per chain): with a frozen proposal the pass is a few microseconds, and sixteen threads watching
+        // the result lines cost the evaluation's last stores more than the earlier start gains (measured).
+        arrive_used = s->arrive_enabled && learn_a && (i % period_a) == 0;
+        if (arrive_used) {
+            // accept on arrival (the pass below then only picks up chains whose result was slow to come, if any)
+            std::atomic<int> perr_a{0};
+            std::fill(s->arrived.begin(), s->arrived.end(), (uint8_t)0);
+            s->pool->run(n, [&](int m) {
+                double Lm = 0.0;
+                int32_t stm = 0;
+                int rp = TAMCMC_PENDING;
+                for (int spin = 0; spin < (1 << 20); spin++) {       // bounded: a failed launch is reported by _end below
+                    rp = tamcmc_eval_batch_poll(s->hip_ctx, m, &Lm, &stm);
+                    if (rp != TAMCMC_PENDING) break;
+                    for (int b = 0; b < 8; b++) __builtin_ia32_pause();      // (easy on the lines the GPU is about to write)
+                }
+                if (rp != TAMCMC_OK) return;
+                s->L_prop[m] = Lm; s->status[m] = stm;
+                accept_chain(s, m, i, gamma, learn_a, period_a, true, perr_a);
+                s->arrived[m] = 1;
+            });
+            if (perr_a.load()) perr_arrive = 1;
+        }
         rc = tamcmc_eval_batch_end(s->hip_ctx, n, s->L_prop.data(), s->status.data());
         t1 = now(); s->t_phase[4] += t1 - t0; t0 = t1;
     } else {
@@ -1227,10 +1276,16 @@ extern "C" int tamcmc_sampler_mh_step(tamcmc_sampler *s)
     auto accept = [&](int m) { accept_chain(s, m, i, gamma, learn, period, ahead, perr_any); };
     // (the fixed chain -> thread map of the pool keeps a chain's rows in the cache of the core that proposed them:
     // even the short accept step without adaptation is cheaper forked than pulled over to the calling thread)
-    s->pool->run(n, accept);
+    if (arrive_used) {
+        int left = 0;
+        for (int m = 0; m < n; m++) left += s->arrived[m] ? 0 : 1;
+        if (left) s->pool->run(n, [&](int m) { if (!s->arrived[m]) accept(m); });
+    } else {
+        s->pool->run(n, accept);
+    }
     s->proposed_ahead = ahead;
     t1 = now(); s->t_phase[5] += t1 - t0; s->t_iters++;
-    const int perr = perr_any.load();
+    const int perr = perr_any.load() | perr_arrive;
     return perr ? TAMCMC_E_INVALID : TAMCMC_OK;
 }
 
@@ -1326,9 +1381,22 @@ extern "C" int tamcmc_sampler_pt_import(tamcmc_sampler *s, int32_t A, double u, 
 
 extern "C" int tamcmc_sampler_end_iteration(tamcmc_sampler *s) { if (!s) return TAMCMC_E_INVALID; s->iter++; return TAMCMC_OK; }
 
+// An armed evaluation must not outlive the loop that armed it (an error return, or a caller that goes on to use the
+// context directly): on the way out of a run call its gate is opened and the batch waited for.
+struct ArmGuard {
+    tamcmc_sampler *s;
+    ~ArmGuard()
+    {
+        s->arm_next = false;
+        if (s->ctx_armed && s->hip_ctx) (void)tamcmc_eval_batch_disarm(s->hip_ctx);
+        s->ctx_armed = false;
+    }
+};
+
 extern "C" int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *moved_hist, int32_t *swap_hist)
 {
     if (!s || s->nloc != s->cfg.Nchains) return TAMCMC_E_INVALID;   // single process only
+    ArmGuard guard{s};
     for (int64_t k = 0; k < n_iter; k++) {
         int32_t sh = -1;
         auto pt_step = [&]() {
@@ -1344,6 +1412,7 @@ extern "C" int tamcmc_sampler_run(tamcmc_sampler *s, int64_t n_iter, uint8_t *mo
             rc = pipelined_iteration(s, k + 1 < n_iter, moved_hist ? moved_hist + (size_t)k * s->nloc : nullptr, pt_step);
             if (rc != TAMCMC_OK) return rc;
         } else {
+            s->arm_next = (k + 1 < n_iter);
             rc = tamcmc_sampler_mh_step(s);
             if (rc != TAMCMC_OK) return rc;
             if (moved_hist) std::memcpy(moved_hist + (size_t)k * s->nloc, s->moved.data(), s->nloc);
@@ -1440,6 +1509,7 @@ extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tam
     std::vector<double> send((size_t)nrec), recv((size_t)nrec);
     int64_t k = 0;
     struct Done { int64_t *p; const int64_t &k; ~Done() { if (p) *p = k; } } report{done, k};   // also on the error returns
+    ArmGuard guard{s};
     for (; k < n_iter; k++) {
         if (block && block->n >= block->cap) break;                    // the caller gathers the block, resets it, calls again
         double att = 0.0, Ad = -1.0, r = std::numeric_limits<double>::quiet_NaN(), swd = -1.0;
@@ -1475,6 +1545,7 @@ extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tam
             rc = pipelined_iteration(s, more, moved_hist ? moved_hist + (size_t)k * nloc : nullptr, pt_step);
             if (rc != TAMCMC_OK) return rc;
         } else {
+            s->arm_next = (k + 1 < n_iter) && !(block && block->n + 1 >= block->cap);
             rc = tamcmc_sampler_mh_step(s);
             if (rc != TAMCMC_OK) return rc;
             if (moved_hist) std::memcpy(moved_hist + (size_t)k * nloc, s->moved.data(), (size_t)nloc);

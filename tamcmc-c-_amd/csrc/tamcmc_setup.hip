@@ -47,3 +47,26 @@ int tm_launch_setup(const TmLayout &L, int Nchains, const double *d_params, cons
 
 size_t tm_sizeof_chain_rec() { return sizeof(TmChain); }
 size_t tm_sizeof_aux() { return sizeof(TmMultFull); }
+
+// Gate of an armed batch (tamcmc_eval_batch_arm / _fire, tamcmc_api.cpp): one wave that holds the stream until the host
+// has put the batch's parameters into the pinned input buffer and stored `target` into the pinned word `gate`.  The
+// launches of the batch sit behind it in the stream, so what the host pays between knowing the parameters and the GPU
+// starting on them is one store, not two kernel launches.  The wait is bounded (~2 s): a wave must never outlive its
+// host (a host that dies before firing leaves a gate that gives up; the batch then runs on the previous parameters and
+// nobody collects it).
+__global__ __launch_bounds__(64) void tamcmc_gate_kernel(const uint32_t *gate, uint32_t target)
+{
+    if (threadIdx.x == 0) {
+        for (int spin = 0; spin < (1 << 21); spin++) {
+            const uint32_t v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int32_t)(v - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+}
+
+int tm_launch_gate(const uint32_t *dv_gate, uint32_t target, void *stream)
+{
+    hipLaunchKernelGGL(tamcmc_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dv_gate, target);
+    return (int)hipGetLastError();
+}

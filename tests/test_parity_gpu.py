@@ -474,6 +474,56 @@ def test_likelihood_and_gradient_paths_return_the_same_logL_bits(accel_mod, orc,
     assert np.all(st == 0) and np.array_equal(L, Lg)
 
 
+def test_armed_batches_equal_plain_batches(accel_mod, orc):
+    """tamcmc_eval_batch_arm / _fire / _disarm: the launches of the next batch wait in the stream behind a gate while the
+    current one is evaluated, and run on the parameters handed to _fire -- results bit for bit those of a plain batch,
+    over many rounds with changing parameters (the gate value wraps nothing, buffers are reused); an armed batch that is
+    never fired is disarmed (explicitly, and by destroying the context) without a hang; misuse is refused."""
+    w = synth.workload_c2(Nx=40000)
+    y = spectrum_for(orc, w)
+    n = 16
+    T = synth.temperatures(n)
+    P = [synth.chain_params(w, n, seed=300 + k) for k in range(10)]
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        ref = [acc.eval_batch(Pk, T) for Pk in P]
+        acc.begin(P[0], T)
+        for k in range(1, len(P)):
+            acc.arm(n)                                   # under batch k-1, still in flight
+            L, st = acc.end()
+            assert np.array_equal(L, ref[k - 1][0]) and np.array_equal(st, ref[k - 1][1])
+            acc.fire(P[k], T)
+        # results arrive chain by chain: poll() hands each one out once it is there (None before), _end is still due
+        got, tries = {}, 0
+        while len(got) < n and tries < 10 ** 7:
+            for m in range(n):
+                if m not in got:
+                    r = acc.poll(m)
+                    if r is not None:
+                        got[m] = r
+            tries += 1
+        assert len(got) == n
+        assert np.array_equal(np.array([got[m][0] for m in range(n)]), ref[-1][0])
+        assert np.array_equal(np.array([got[m][1] for m in range(n)], dtype=np.int32), ref[-1][1])
+        with pytest.raises(accel_mod.AccelError):
+            acc.poll(n)                                  # not a chain of the batch
+        acc.arm(n)
+        for bad in (lambda: acc.begin(P[0], T), lambda: acc.eval_batch(P[0], T), lambda: acc.arm(n), lambda: acc.reserve(4 * n),
+                    lambda: acc.disarm()):              # (a batch is in flight: collect it first)
+            with pytest.raises(accel_mod.AccelError):
+                bad()
+        L, st = acc.end()
+        assert np.array_equal(L, ref[-1][0]) and np.array_equal(st, ref[-1][1])
+        with pytest.raises(accel_mod.AccelError):
+            acc.fire(P[0][:8], T[:8])                    # not the armed size
+        acc.disarm()                                     # never fired: runs on the previous parameters, nothing handed out
+        acc.disarm()                                     # (idempotent)
+        L, st = acc.eval_batch(P[3], T)                  # the context is fine afterwards
+        assert np.array_equal(L, ref[3][0])
+        rL, _ = orc.generate_batch(2, w["plength"], w["x"], y, P[3], T)
+        check_logL(L, rL)
+        acc.arm(n)                                       # ... and a context destroyed with a batch armed does not hang
+
+
 def test_two_parts_in_flight_equal_one_batch(accel_mod, orc):
     """tamcmc_eval_batch_begin_part / _end_part: two halves of a batch in flight together (part 1 on its own stream, per-chain
     buffers offset by the part's first chain), ended in either order, uneven halves, many rounds with changing parameters:

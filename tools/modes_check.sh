@@ -8,7 +8,8 @@ rc=0
 for cfg in "TAMCMC_EQUAL_COST=1" "TAMCMC_ORDER=0" "TAMCMC_ORDER=1 TAMCMC_PRIO=1" \
            "TAMCMC_FUSED=0" "TAMCMC_BG_EXACT=1" \
            "TAMCMC_TILES=31 TAMCMC_TILES_GRAD=37 TAMCMC_EQUAL_COST=1" \
-           "TAMCMC_TAIL=0" "TAMCMC_TAIL=60,3 TAMCMC_TAIL_L=80,5" "TAMCMC_SAMPLER_PIPELINE=2" "TAMCMC_SAMPLER_PIPELINE=3"; do
+           "TAMCMC_TAIL=0" "TAMCMC_TAIL=60,3 TAMCMC_TAIL_L=80,5" "TAMCMC_SAMPLER_PIPELINE=2" "TAMCMC_SAMPLER_PIPELINE=3" \
+           "TAMCMC_SAMPLER_ARM=0" "TAMCMC_SAMPLER_ARRIVE=0" "TAMCMC_SAMPLER_ARM=0 TAMCMC_SAMPLER_ARRIVE=0"; do
     echo "== $cfg"
     # the resource test reads the code object, not the switches
     env $cfg timeout -k 10 300 python -m pytest tests -m gpu -q -x \
