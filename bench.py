@@ -306,11 +306,16 @@ def run_rank(args):
         smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], w["err"])
         smp.init()
         smp.run(200, history=False)
-        n_s = max(50, min(10 * args.steps, 2000))      # ~0.25 s per leg: shorter legs scatter by 20 %
-        t0 = time.perf_counter()
-        moved, _ = smp.run(n_s)
-        el = time.perf_counter() - t0
+        n_s = max(50, min(10 * args.steps, 2000))      # ~0.2 s per segment: shorter ones scatter by 20 %
+        # three segments, the median reported (the host threads share a many-tenant machine: single segments scatter by +-5 %)
+        seg = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            moved, _ = smp.run(n_s)
+            seg.append(time.perf_counter() - t0)
+        el = sorted(seg)[1]
         sampler_rate = {"iterations_per_s": round(n_s / el, 1), "chain_steps_per_s": round(nchains * n_s / el, 1),
+                        "segments_iterations_per_s": [round(n_s / e, 1) for e in seg],
                         "acceptance_cold_chain": round(float(moved[:, 0].mean()), 3),
                         "what": "adaptive Metropolis + parallel tempering (the reference's 'MALA' has no gradient), host C++ "
                                 "sampler, likelihood on the GPU through tamcmc_eval_batch_begin/_end (host pointers); proposal adapted "
@@ -321,9 +326,13 @@ def run_rank(args):
         smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], 0.05 * w["err"])
         smp.init()
         smp.run(200, history=False)
-        t0 = time.perf_counter()
-        smp.run(n_s, history=False)
-        el = time.perf_counter() - t0
+        seg = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            smp.run(n_s, history=False)
+            seg.append(time.perf_counter() - t0)
+        el = sorted(seg)[1]
+        sampler_rate["acquire_phase_segments_iterations_per_s"] = [round(n_s / e, 1) for e in seg]
         sampler_rate["acquire_phase_iterations_per_s"] = round(n_s / el, 1)
         sampler_rate["acquire_phase_chain_steps_per_s"] = round(nchains * n_s / el, 1)
         smp.close()
