@@ -33,7 +33,8 @@
  *   TAMCMC_BG_EXACT=1                 Harvey background by exp() per bin instead of the per-cell polynomial
  *   TAMCMC_TAIL="frac,su2" | 0        gradient launch on long grids: 8-unit tiles for frac % of the units, su2-unit tiles for the
  *                                     rest (default "85,4"; 0: all tiles alike); TAMCMC_TAIL_L the same for the likelihood launch (default off)
- * (tamcmc_sampler.h: TAMCMC_SAMPLER_THREADS, TAMCMC_SAMPLER_TIMING, TAMCMC_SAMPLER_PIPELINE.)
+ *   TAMCMC_GATE_PATIENCE=n            polls (~2 us each) before the gate of an armed batch gives up (default 2^21: ~4 s; tests)
+ * (tamcmc_sampler.h: TAMCMC_SAMPLER_THREADS, TAMCMC_SAMPLER_TIMING, TAMCMC_SAMPLER_PIPELINE, TAMCMC_SAMPLER_ARM, TAMCMC_SAMPLER_ARRIVE.)
  *
  * Threading: one ctx = one device + one stream; calls on one ctx must be serialised by the caller;
  * different ctx objects (other GPUs, other stars) may be driven concurrently from different threads.
@@ -142,7 +143,9 @@ int tamcmc_eval_batch_end(tamcmc_ctx *ctx, int32_t Nchains, double *logL, int32_
  * the place of _begin, and _end collects the results as usual.  While a batch is armed every other entry point of the
  * context returns TAMCMC_E_INVALID except _fire, _end (of the batch in flight), _disarm and tamcmc_ctx_destroy.  _disarm
  * opens the gate of a batch that will not be fired (it runs on the previous parameters, is waited for, and nothing is
- * handed out).  The gate itself gives up after ~2 s: a wave never outlives a host that died before firing. */
+ * handed out).  The gate itself gives up after ~4 s, so that a wave never outlives a host that died before firing; a
+ * host that was merely held up that long loses time, not a result: _fire notices that the gate has expired (the armed
+ * launches ran on stale input), lets them drain and evaluates the batch the plain way. */
 int tamcmc_eval_batch_arm(tamcmc_ctx *ctx, int32_t Nchains);
 /* One chain of the batch in flight (_begin / _fire, not yet _end): TAMCMC_OK with its logL and status once they have
  * arrived, TAMCMC_PENDING before.  Results arrive chain by chain (each is finalized by the last of its tiles), so a host

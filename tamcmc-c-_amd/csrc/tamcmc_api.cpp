@@ -80,6 +80,7 @@ struct tamcmc_ctx {
     int armed = 0;                 // chains of a tamcmc_eval_batch_arm whose launches wait behind the gate for _fire
     uint32_t *h_gate = nullptr, *dv_gate = nullptr;   // pinned word the gate kernel watches
     uint32_t gate_seq = 0;         // value that opens the gate of the armed batch
+    int gate_patience = 1 << 21;   // polls (~2 us each) before the gate gives up; TAMCMC_GATE_PATIENCE (tests)
     // tamcmc_eval_batch_begin_part / _end_part: two sub-batches of the context's chains in flight at once, part 1 on a
     // stream of its own; a part's rows of every per-chain buffer start at its first chain
     hipStream_t part_streams[TAMCMC_MAX_PARTS] = {};      // [0] unused (part 0 runs on the context stream), created on demand
@@ -287,6 +288,7 @@ extern "C" int tamcmc_ctx_create(tamcmc_ctx **out, int device_id, int model_case
     env_int("TAMCMC_ORDER", 0, 2, &c->order_mode);
     env_int("TAMCMC_FUSED", 0, 1, &c->fuse);
     env_int("TAMCMC_EQUAL_COST", 0, 1, &c->equal_cost);
+    env_int("TAMCMC_GATE_PATIENCE", 1, 1 << 30, &c->gate_patience);
     env_int("TAMCMC_PRIO", 0, 1, &c->prio);
     auto env_cost = [](const char *name, TmCostModel *m) {
         const char *e = getenv(name);
@@ -814,7 +816,17 @@ extern "C" int tamcmc_eval_batch_poll(const tamcmc_ctx *c, int32_t chain, double
     return TAMCMC_OK;
 }
 
-int tm_launch_gate(const uint32_t *dv_gate, uint32_t target, void *stream);      // tamcmc_setup.hip
+int tm_launch_gate(uint32_t *dv_gate, uint32_t target, int patience, void *stream);      // tamcmc_setup.hip
+#define TM_GATE_EXPIRED 16
+#define TM_GATE_FIRING 32
+
+// The host's side of the gate's expiry protocol (tamcmc_setup.hip): announce, then look.  true: the gate has given up and
+// the armed launches ran (or are running) on stale input -- the caller opens the word anyway, lets them drain and starts over.
+static bool gate_claim(tamcmc_ctx *c)
+{
+    __atomic_store_n(c->h_gate + TM_GATE_FIRING, c->gate_seq, __ATOMIC_SEQ_CST);
+    return __atomic_load_n(c->h_gate + TM_GATE_EXPIRED, __ATOMIC_SEQ_CST) == c->gate_seq;
+}
 
 // An armed batch: its launches are put into the stream AHEAD of its parameters, behind a one-wave gate kernel that
 // watches a pinned word.  A host loop arms batch i+1 while the GPU evaluates batch i (the launch calls, ~6 us, are then
@@ -831,12 +843,14 @@ extern "C" int tamcmc_eval_batch_arm(tamcmc_ctx *c, int32_t Nchains)
     }
     TM_HIP(hipSetDevice(c->device));
     if (!c->h_gate) {
-        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_gate), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        TM_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_gate), 256, hipHostMallocMapped | hipHostMallocCoherent));
         TM_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->dv_gate), c->h_gate, 0));
+        std::memset(c->h_gate, 0, 256);
+        c->gate_seq = 1;               // (0 is what the expiry / firing words hold before the first batch)
         *c->h_gate = c->gate_seq;
     }
     const uint32_t target = c->gate_seq + 1;
-    int rc = tm_launch_gate(c->dv_gate, target, c->stream);
+    int rc = tm_launch_gate(c->dv_gate, target, c->gate_patience, c->stream);
     if (rc != 0) { snprintf(g_hip_err, sizeof(g_hip_err), "gate launch -> %s", hipGetErrorString((hipError_t)rc)); return TAMCMC_E_HIP; }
     const size_t n = (size_t)Nchains;
     rc = enqueue(c, Nchains, c->dv_in, c->dv_in + n * c->L.Nparams, c->dv_out, nullptr, c->dv_status, nullptr, nullptr);
@@ -852,6 +866,14 @@ extern "C" int tamcmc_eval_batch_arm(tamcmc_ctx *c, int32_t Nchains)
 extern "C" int tamcmc_eval_batch_fire(tamcmc_ctx *c, int32_t Nchains, int32_t Nparams, const double *params, const double *Tcoefs)
 {
     if (!c || !params || !Tcoefs || Nparams != c->L.Nparams || c->armed != Nchains || Nchains < 1 || c->in_flight) return TAMCMC_E_INVALID;
+    if (gate_claim(c)) {
+        // the gate gave up waiting (the host was held up for seconds): the armed launches used stale input.  Let them
+        // drain and evaluate this batch the plain way.
+        __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE);
+        c->armed = 0;
+        TM_HIP(hipStreamSynchronize(c->stream));
+        return tamcmc_eval_batch_begin(c, Nchains, Nparams, params, Tcoefs);
+    }
     const size_t n = (size_t)Nchains;
     std::memcpy(c->h_in, params, n * Nparams * sizeof(double));
     std::memcpy(c->h_in + n * Nparams, Tcoefs, n * sizeof(double));
@@ -871,6 +893,12 @@ extern "C" int tamcmc_eval_batch_disarm(tamcmc_ctx *c)
     if (!c->armed) return TAMCMC_OK;
     if (c->in_flight) return TAMCMC_E_INVALID;        // collect the batch in flight first (_end)
     const int n = c->armed;
+    if (gate_claim(c)) {              // it has run (or is running) already: just let it retire
+        __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE);
+        c->armed = 0;
+        TM_HIP(hipStreamSynchronize(c->stream));
+        return TAMCMC_OK;
+    }
     mark_pending(c, n, (size_t)n);
     __atomic_store_n(c->h_gate, c->gate_seq, __ATOMIC_RELEASE);
     c->ev_recorded = false;

@@ -49,24 +49,36 @@ size_t tm_sizeof_chain_rec() { return sizeof(TmChain); }
 size_t tm_sizeof_aux() { return sizeof(TmMultFull); }
 
 // Gate of an armed batch (tamcmc_eval_batch_arm / _fire, tamcmc_api.cpp): one wave that holds the stream until the host
-// has put the batch's parameters into the pinned input buffer and stored `target` into the pinned word `gate`.  The
+// has put the batch's parameters into the pinned input buffer and stored `target` into the pinned word gate[0].  The
 // launches of the batch sit behind it in the stream, so what the host pays between knowing the parameters and the GPU
-// starting on them is one store, not two kernel launches.  The wait is bounded (~2 s): a wave must never outlive its
-// host (a host that dies before firing leaves a gate that gives up; the batch then runs on the previous parameters and
-// nobody collects it).
-__global__ __launch_bounds__(64) void tamcmc_gate_kernel(const uint32_t *gate, uint32_t target)
+// starting on them is one store, not two kernel launches.
+// A wave must never outlive its host, so the wait is bounded (`patience` polls, ~2 us each: ~4 s by default).  When it
+// runs out the gate says so in gate[TM_GATE_EXPIRED] and lets the batch run on whatever the input buffer holds; the
+// host looks at that word when it fires and, if the gate has given up, throws the stale batch away and launches again
+// (a host that was merely slow -- a debugger, a device-wide synchronisation somewhere else in the process -- loses
+// time, never a result).  The two sides may meet: the host announces itself in gate[TM_GATE_FIRING] before it looks at
+// the expiry word, the gate looks at that announcement after it has written the expiry word (store-then-load on both
+// sides: at least one sees the other); a gate that finds the host firing goes on waiting for the word to open.
+#define TM_GATE_EXPIRED 16     // (uint32 index: one cache line apart)
+#define TM_GATE_FIRING 32
+__global__ __launch_bounds__(64) void tamcmc_gate_kernel(uint32_t *gate, uint32_t target, int patience)
 {
-    if (threadIdx.x == 0) {
-        for (int spin = 0; spin < (1 << 21); spin++) {
-            const uint32_t v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((int32_t)(v - target) >= 0) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
+    if (threadIdx.x != 0) return;
+    auto open = [&]() { return (int32_t)(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) >= 0; };
+    for (int spin = 0; spin < patience; spin++) {
+        if (open()) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __hip_atomic_store(gate + TM_GATE_EXPIRED, target, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__hip_atomic_load(gate + TM_GATE_FIRING, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM) != target) return;   // expired
+    for (int spin = 0; spin < (1 << 20); spin++) {      // the host is firing right now: the word opens within microseconds
+        if (open()) return;
+        __builtin_amdgcn_s_sleep(16);
     }
 }
 
-int tm_launch_gate(const uint32_t *dv_gate, uint32_t target, void *stream)
+int tm_launch_gate(uint32_t *dv_gate, uint32_t target, int patience, void *stream)
 {
-    hipLaunchKernelGGL(tamcmc_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dv_gate, target);
+    hipLaunchKernelGGL(tamcmc_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dv_gate, target, patience);
     return (int)hipGetLastError();
 }

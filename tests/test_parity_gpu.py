@@ -524,6 +524,38 @@ def test_armed_batches_equal_plain_batches(accel_mod, orc):
         acc.arm(n)                                       # ... and a context destroyed with a batch armed does not hang
 
 
+def test_an_expired_gate_costs_time_not_results(accel_mod, orc, monkeypatch):
+    """The gate of an armed batch gives up after TAMCMC_GATE_PATIENCE polls (a wave must not outlive its host).  A host
+    that fires later than that must still get the right answer: _fire sees the expiry, lets the stale launches drain and
+    evaluates the batch the plain way; _disarm of an expired batch just lets it retire."""
+    import time
+    monkeypatch.setenv("TAMCMC_GATE_PATIENCE", "2000")          # ~4 ms
+    w = synth.workload_c2(Nx=20000)
+    y = spectrum_for(orc, w)
+    n = 8
+    T = synth.temperatures(n)
+    P = [synth.chain_params(w, n, seed=400 + k) for k in range(4)]
+    with accel_mod.Accel(2, w["plength"], w["x"], y) as acc:
+        ref = [acc.eval_batch(Pk, T) for Pk in P]
+        acc.begin(P[0], T)
+        acc.arm(n)
+        L, st = acc.end()
+        assert np.array_equal(L, ref[0][0])
+        time.sleep(0.3)                                          # far beyond the gate's patience
+        acc.fire(P[1], T)
+        L, st = acc.end()
+        assert np.array_equal(L, ref[1][0]) and np.array_equal(st, ref[1][1])
+        acc.arm(n)                                               # in time: the normal path again
+        acc.fire(P[2], T)
+        L, st = acc.end()
+        assert np.array_equal(L, ref[2][0])
+        acc.arm(n)
+        time.sleep(0.3)
+        acc.disarm()                                             # expired and never fired
+        L, st = acc.eval_batch(P[3], T)
+        assert np.array_equal(L, ref[3][0]) and np.array_equal(st, ref[3][1])
+
+
 def test_two_parts_in_flight_equal_one_batch(accel_mod, orc):
     """tamcmc_eval_batch_begin_part / _end_part: two halves of a batch in flight together (part 1 on its own stream, per-chain
     buffers offset by the part's first chain), ended in either order, uneven halves, many rounds with changing parameters:
