@@ -249,6 +249,20 @@ struct GlibcRand {
         if (++b >= 31) b = 0;
         return out;
     }
+    // n calls of next() in one go: the ring is unrolled into a line (no wrap-around tests, no pointer updates per value)
+    // and written back with the pointers advanced by n -- the same state the n calls would leave.
+    void fill(int32_t *out, int n)
+    {
+        while (n > 0) {
+            const int m = n < 480 ? n : 480;
+            uint32_t z[31 + 480];
+            for (int i = 0; i < 31; i++) z[i] = (uint32_t)r[(f + i) % 31];          // age order, oldest first
+            for (int i = 31; i < 31 + m; i++) { z[i] = z[i - 31] + z[i - 3]; out[i - 31] = (int32_t)(z[i] >> 1); }
+            f = (f + m) % 31; b = (b + m) % 31;
+            for (int i = 0; i < 31; i++) r[(f + i) % 31] = (int32_t)z[m + i];
+            out += m; n -= m;
+        }
+    }
     // Jump ahead: the state after k more calls of next(), without making them.  The words obey z[n] = z[n-31] + z[n-3]
     // modulo 2^32, a linear recurrence with characteristic polynomial p(x) = x^31 - x^28 - 1, so with
     // G(x) = x^k mod p(x) = sum_j G_j x^j every later word is z[m + k] = sum_j G_j z[m + j].  G costs ~31^2 log2(k)
@@ -352,18 +366,19 @@ struct Rng {
         int n = 0, npairs = 0;         // pairs (cos, sin) written to x[first .. first + 2 npairs)
         int first = 0;                 // 0 or 1 (x[0] taken from the carry)
         bool has_carry_in = false, tail = false;   // tail: one more value (cos part only) after the pairs
-        double carry_in = 0.0;
-        std::vector<double> r;
+        double carry_in = 0.0, tail_x = 0.0;
+        std::vector<int32_t> raw;      // what rand() returned; the uniforms r = raw / 2147483647 (random_JB.cpp:255) are made in fill
+        static double uni(int32_t v) { return (double)v / 2147483647.0; }
         void fill(double *x) const
         {
             const double PI = 3.141592653589793;
             if (has_carry_in) x[0] = carry_in;
             for (int k = 0; k < npairs; k++) {
-                const double a = std::sqrt(-2.0 * std::log(r[2 * k])), ang = 2.0 * PI * r[2 * k + 1];
+                const double a = std::sqrt(-2.0 * std::log(uni(raw[2 * k]))), ang = 2.0 * PI * uni(raw[2 * k + 1]);
                 x[first + 2 * k] = a * std::cos(ang);
                 x[first + 2 * k + 1] = a * std::sin(ang);
             }
-            if (tail) x[first + 2 * npairs] = std::sqrt(-2.0 * std::log(r[2 * npairs])) * std::cos(2.0 * PI * r[2 * npairs + 1]);
+            if (tail) x[first + 2 * npairs] = tail_x;      // made by draw together with the carried sine (see there)
         }
     };
     void draw(int n, NormalPlan &P)
@@ -376,12 +391,17 @@ struct Rng {
         if (cnt == 0) return;
         const bool odd = (cnt % 2) != 0;
         const int nr = odd ? cnt + 1 : cnt;          // uniforms consumed (random_JB.cpp: 2 for cnt == 1, 2m otherwise)
-        if ((int)P.r.size() < nr) P.r.resize(nr);
-        for (int k = 0; k < nr; k++) P.r[k] = uniform();
+        if ((int)P.raw.size() < nr) P.raw.resize(nr);
+        g.fill(P.raw.data(), nr);                     // (the serial part of an iteration's draws: only the raw stream)
         P.npairs = cnt / 2;
         P.tail = odd;
-        if (odd) {                                    // the sin part of the last pair is kept for the next call
-            y = std::sqrt(-2.0 * std::log(P.r[nr - 2])) * std::sin(2.0 * PI * P.r[nr - 1]);
+        if (odd) {
+            // The last pair: its cosine part is the call's last value, its sine part is kept for the next call.  Both are
+            // made HERE, side by side as in r8vec_normal_01 (random_JB.cpp:185-190): a compiler turns the adjacent
+            // cos / sin of one angle into one sincos call, whose cosine can differ in the last bit from a lone cos().
+            const double r0 = NormalPlan::uni(P.raw[nr - 2]), r1 = NormalPlan::uni(P.raw[nr - 1]);
+            P.tail_x = std::sqrt(-2.0 * std::log(r0)) * std::cos(2.0 * PI * r1);
+            y = std::sqrt(-2.0 * std::log(r0)) * std::sin(2.0 * PI * r1);
             saved = 1;
         }
     }

@@ -252,6 +252,11 @@ def test_split_normal_generator_equals_the_one_piece_routine():
     a = S.normals(123, sizes, split=False)
     b = S.normals(123, sizes, split=True)
     assert np.array_equal(a, b) and np.all(np.isfinite(a)) and abs(a.mean()) < 0.5
+    # many odd counts, several seeds: the cosine of a call's last pair has to come out of the same sin / cos pair as in
+    # the one-piece routine (a lone cos() differed from it in the last bit once in ~9000 values: seed 5 below)
+    for seed in (5, 77, 2024):
+        sizes = [44, 7, 1, 3, 2, 44, 5, 9, 1, 1, 12] * 50
+        assert np.array_equal(S.normals(seed, sizes, split=False), S.normals(seed, sizes, split=True)), seed
 
 
 def test_thread_count_does_not_change_the_chains(orc, monkeypatch):
