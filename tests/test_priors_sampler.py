@@ -257,6 +257,9 @@ def test_split_normal_generator_equals_the_one_piece_routine():
     for seed in (5, 77, 2024):
         sizes = [44, 7, 1, 3, 2, 44, 5, 9, 1, 1, 12] * 50
         assert np.array_equal(S.normals(seed, sizes, split=False), S.normals(seed, sizes, split=True)), seed
+    # calls longer than one block of the raw generator (GlibcRand::fill unrolls the ring 480 values at a time)
+    sizes = [2000, 481, 480, 479, 961, 1, 31, 62, 1443]
+    assert np.array_equal(S.normals(9, sizes, split=False), S.normals(9, sizes, split=True))
 
 
 def test_thread_count_does_not_change_the_chains(orc, monkeypatch):
