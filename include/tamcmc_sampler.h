@@ -28,7 +28,8 @@
  * library: the local chains as two sub-batches in flight, one handled on the host while the GPU evaluates the other;
  * same draws and decisions; off by default, measured slower at 64 chains x 1e5 bins), TAMCMC_SAMPLER_ARM=0 (HIP evaluator:
  * do NOT put the next iteration's launches into the stream ahead of its parameters -- tamcmc_eval_batch_arm / _fire, on by
- * default inside tamcmc_sampler_run / _run_sharded), TAMCMC_SAMPLER_ARRIVE=0 (HIP evaluator: wait for the whole batch
+ * default inside tamcmc_sampler_run, and inside _run_sharded when the process owns every chain; =2: also when the chains
+ * are spread over several processes, where the boundary exchange runs between arming and firing), TAMCMC_SAMPLER_ARRIVE=0 (HIP evaluator: wait for the whole batch
  * before the accept pass instead of running a chain's accept step when its own result has arrived --
  * tamcmc_eval_batch_poll, on by default).  None of them changes a draw or a decision.
  */

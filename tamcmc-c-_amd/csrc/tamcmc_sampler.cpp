@@ -592,7 +592,7 @@ struct tamcmc_sampler {
     // (tamcmc_eval_batch_arm: they wait behind a gate kernel), so that between the accept step and the GPU starting on the
     // new proposals there is one store instead of two kernel launches.  Only inside tamcmc_sampler_run / _run_sharded,
     // which know that another iteration follows (arm_next); TAMCMC_SAMPLER_ARM=0 turns it off.
-    bool arm_enabled = true, arm_next = false, ctx_armed = false;
+    bool arm_enabled = true, arm_sharded = false, arm_next = false, ctx_armed = false;
     // Results arrive chain by chain (tamcmc_eval_batch_poll): the accept pass is forked BEFORE they are there, every
     // participant watches the chains it owns and runs a chain's accept step the moment its logL has landed -- the fork
     // and most of the pass are then under the evaluation's tail.  TAMCMC_SAMPLER_ARRIVE=0: wait for the whole batch first.
@@ -700,7 +700,7 @@ static int sampler_alloc(tamcmc_sampler **out, const tamcmc_sampler_cfg *cfg, ta
         if (nt < 1) nt = 1;
         s->pool.reset(new ChainPool(nt));
     { const char *e = getenv("TAMCMC_SAMPLER_TIMING"); s->timing = e && e[0] == '1'; }
-    { const char *e = getenv("TAMCMC_SAMPLER_ARM"); s->arm_enabled = !(e && e[0] == '0'); }
+    { const char *e = getenv("TAMCMC_SAMPLER_ARM"); s->arm_enabled = !(e && e[0] == '0'); s->arm_sharded = e && e[0] == '2'; }
     { const char *e = getenv("TAMCMC_SAMPLER_ARRIVE"); s->arrive_enabled = !(e && e[0] == '0'); }
     s->arrived.assign((size_t)n, 0);
     {   // Two halves in flight (pipelined_iteration) with the draws on a thread of their own: OFF unless
@@ -1565,7 +1565,12 @@ extern "C" int tamcmc_sampler_run_sharded(tamcmc_sampler *s, int64_t n_iter, tam
             rc = pipelined_iteration(s, more, moved_hist ? moved_hist + (size_t)k * nloc : nullptr, pt_step);
             if (rc != TAMCMC_OK) return rc;
         } else {
-            s->arm_next = (k + 1 < n_iter) && !(block && block->n + 1 >= block->cap);
+            // (chains spread over several processes: between this step and the next lies the boundary exchange, which
+            // runs the caller's communication library on the same GPU while the armed launches would wait behind their
+            // gate.  Nothing in that is known to synchronise the device, but it cannot be tried on the one-GPU boxes this
+            // was developed on, and a device-wide wait under an armed batch costs the gate's whole patience: armed only
+            // when this process owns the whole ladder, or on request -- TAMCMC_SAMPLER_ARM=2.)
+            s->arm_next = (k + 1 < n_iter) && !(block && block->n + 1 >= block->cap) && (nloc == s->cfg.Nchains || s->arm_sharded);
             rc = tamcmc_sampler_mh_step(s);
             if (rc != TAMCMC_OK) return rc;
             if (moved_hist) std::memcpy(moved_hist + (size_t)k * nloc, s->moved.data(), (size_t)nloc);
