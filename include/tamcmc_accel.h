@@ -66,7 +66,9 @@ typedef struct tamcmc_ctx tamcmc_ctx;
 
 /* per-chain status written by the eval calls */
 #define TAMCMC_CHAIN_OK            0
-#define TAMCMC_CHAIN_NAN           1  /* logL is NaN: legal, means "reject" (MALA.cpp:475,507-509)            */
+#define TAMCMC_CHAIN_NAN           1  /* logL is NaN: legal, means "reject" (MALA.cpp:475,507-509).  Also where a
+                                         width over- or underflows (AppWidth with an absurd exponent): the reference's
+                                         formula stays finite there and loses the move by ~1e4 in logL -- same decision */
 #define TAMCMC_CHAIN_EMPTY_WINDOW  2  /* a truncation window is empty: the reference would exit(EXIT_FAILURE),
                                          build_lorentzian.cpp:428-443; logL is set to NaN                      */
 #define TAMCMC_CHAIN_INTERNAL      3  /* internal consistency check of the tile balancer failed (never expected);
