@@ -403,6 +403,7 @@ extern "C" int tamcmc_ctx_destroy(tamcmc_ctx *c)
 
 extern "C" int tamcmc_ctx_set_vars(tamcmc_ctx *c, int32_t Nvars, const int32_t *index_to_relax)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c || Nvars < 0 || (Nvars > 0 && !index_to_relax)) return TAMCMC_E_INVALID;
     for (int i = 0; i < Nvars; i++)
         if (index_to_relax[i] < 0 || index_to_relax[i] >= c->L.Nparams) return TAMCMC_E_INVALID;
@@ -424,6 +425,7 @@ extern "C" int tamcmc_ctx_set_vars(tamcmc_ctx *c, int32_t Nvars, const int32_t *
 
 extern "C" int tamcmc_ctx_set_spectra(tamcmc_ctx *c, int32_t Nspectra, const double *y, const double *sigma_y)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c || Nspectra < 1 || !y || (c->L.likelihood_case == 1 && !sigma_y)) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
@@ -447,6 +449,7 @@ extern "C" int tamcmc_ctx_set_spectra(tamcmc_ctx *c, int32_t Nspectra, const dou
 
 extern "C" int tamcmc_ctx_set_chain_spectrum(tamcmc_ctx *c, int32_t Nchains, const int32_t *spectrum_of_chain)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c || Nchains < 0 || (Nchains > 0 && !spectrum_of_chain)) return TAMCMC_E_INVALID;
     for (int m = 0; m < Nchains; m++)
         if (spectrum_of_chain[m] < 0 || spectrum_of_chain[m] >= c->nspec) return TAMCMC_E_INVALID;
@@ -463,6 +466,7 @@ extern "C" int tamcmc_ctx_set_chain_spectrum(tamcmc_ctx *c, int32_t Nchains, con
 
 extern "C" int tamcmc_ctx_set_stream(tamcmc_ctx *c, void *hip_stream)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
@@ -472,6 +476,7 @@ extern "C" int tamcmc_ctx_set_stream(tamcmc_ctx *c, void *hip_stream)
 
 extern "C" int tamcmc_ctx_synchronize(tamcmc_ctx *c)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
@@ -498,6 +503,7 @@ extern "C" int tamcmc_ctx_profile(tamcmc_ctx *c, int enable)
 
 extern "C" int tamcmc_ctx_kernel_time(tamcmc_ctx *c, double *total_ms, int64_t *launches)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c || !total_ms || !launches) return TAMCMC_E_INVALID;
     TM_HIP(hipSetDevice(c->device));
     TM_HIP(hipStreamSynchronize(c->stream));
@@ -668,6 +674,7 @@ extern "C" int tamcmc_eval_batch_device(tamcmc_ctx *c, int32_t Nchains, int32_t 
                                         const double *d_params, const double *d_Tcoefs,
                                         double *d_logL, double *d_grad, int32_t *d_status)
 {
+    if (c && c->armed) return TAMCMC_E_INVALID;     // launches wait behind a gate: only _fire / _end / _disarm / destroy (tamcmc_accel.h)
     if (!c || Nchains < 1 || !d_params || !d_Tcoefs || !d_logL) return TAMCMC_E_INVALID;
     if (Nparams != c->L.Nparams || c->parts_busy()) return TAMCMC_E_INVALID;
     if (d_grad) { int rc = grad_supported(c); if (rc != TAMCMC_OK) return rc; }

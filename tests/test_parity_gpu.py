@@ -508,6 +508,7 @@ def test_armed_batches_equal_plain_batches(accel_mod, orc):
             acc.poll(n)                                  # not a chain of the batch
         acc.arm(n)
         for bad in (lambda: acc.begin(P[0], T), lambda: acc.eval_batch(P[0], T), lambda: acc.arm(n), lambda: acc.reserve(4 * n),
+                    lambda: acc.set_stream(0), lambda: acc.synchronize(),        # (would wait for the gate)
                     lambda: acc.disarm()):              # (a batch is in flight: collect it first)
             with pytest.raises(accel_mod.AccelError):
                 bad()
