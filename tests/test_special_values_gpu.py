@@ -86,7 +86,7 @@ def test_special_parameter_values(accel_mod, orc, mid):
             if rst[k] != 0 or not np.isfinite(rL[k]):
                 continue
             assert abs(L[k] - rL[k]) <= 1e-10 * abs(rL[k]), (tag, L[k], rL[k])
-            assert L[k] == L2[k], tag
+            assert abs(L[k] - L2[k]) <= 1e-12 * abs(L2[k]), tag       # (the two launches may cut the grid into different tiles)
             if gst[k] != 0:
                 continue
             if kind == "inc90":
