@@ -302,6 +302,7 @@ def run_rank(args):
     sampler_rate = None
     if rank == 0 and world == 1 and not args.no_sampler:
         from tamcmc_amd import sampler as S
+        acc.set_stream(0)      # the context's own (non-blocking) stream: the loop keeps launches armed behind a gate kernel
         cfg = S.default_cfg(nchains, seed=7, Nt_learn=(20, 60, 10 ** 9), periods_learn=(1, 1), prior_fct_switch=0, dN_mixing=1)
         smp = S.Sampler(cfg, acc, w["plength"], w["params_true"], w["relax"], w["err"])
         smp.init()
