@@ -1,5 +1,6 @@
 """Developer probe: HIP gradient against the oracle's analytic gradient, entry by entry (window on), printing for every
-case the worst |dg|/|g| and the worst |dg| / sum|terms| (the entry's conditioning).  Usage: python tools/grad_entry_probe.py"""
+case the worst |dg|/|g| and the worst |dg| / sum|terms| (the entry's conditioning).  Usage: python tests/grad_entry_probe.py
+(kept under tests/: it uses the oracle, which only tests, smoke() and bench.py's cpu_baseline leg may touch)"""
 import os
 import sys
 import time
