@@ -1,7 +1,8 @@
 // tamcmc_backward.hip -- chain rule from the eval kernel's per-multiplet partial sums to
 // d(logL/T)/d vars.  NOT in the reference (its sampler never had a gradient: MALA.cpp:18,317-333;
-// SURVEY.md F2 / App. D): this is new functionality, validated against finite differences of the
-// CPU oracle's log-likelihood only ("parity unpinned").  The truncation window [imin,imax) moves
+// SURVEY.md F2 / App. D): this is new functionality, validated entry by entry against an analytic gradient
+// written independently into the CPU oracle (itself pinned against long-double finite differences of its
+// log-likelihood; no reference output exists: "parity unpinned").  The truncation window [imin,imax) moves
 // with the parameters; like any analytic gradient of a truncated model this ignores the motion.
 //
 // One workgroup (512 threads) per chain.  The chain record (TmChain) and the per-multiplet records
