@@ -65,6 +65,17 @@ def test_argument_validation_happens_before_device_use(accel_mod):
     assert lib.tamcmc_ctx_create(C.byref(ctx), 0, 2, 7, 1.0, pl, 16, xp, xp, None) == accel_mod.capi.E_UNKNOWN_MODEL
     assert lib.tamcmc_ctx_create(C.byref(ctx), 0, 2, 0, 1.0, pl, 1, xp, xp, None) == accel_mod.capi.E_INVALID
     assert lib.tamcmc_ctx_create(None, 0, 2, 0, 1.0, pl, 16, xp, xp, None) == accel_mod.capi.E_INVALID
+    # the batch entry points without a context: an error code, not a crash (no device is touched)
+    L, st = C.c_double(), C.c_int32()
+    assert lib.tamcmc_eval_batch_arm(None, 4) == accel_mod.capi.E_INVALID
+    assert lib.tamcmc_eval_batch_fire(None, 4, 3, xp, xp) == accel_mod.capi.E_INVALID
+    assert lib.tamcmc_eval_batch_disarm(None) == accel_mod.capi.E_INVALID
+    assert lib.tamcmc_eval_batch_poll(None, 0, C.byref(L), C.byref(st)) == accel_mod.capi.E_INVALID
+    assert lib.tamcmc_eval_batch_begin(None, 4, 3, xp, xp) == accel_mod.capi.E_INVALID
+    assert lib.tamcmc_ctx_reserve(None, 4) == accel_mod.capi.E_INVALID
+    A = np.array([[4.0, 2.0], [2.0, 3.0]]); Lc = np.zeros((2, 2))
+    assert lib.tamcmc_host_cholesky(A.ctypes.data_as(dp), 2, Lc.ctypes.data_as(dp)) == 0 and np.allclose(Lc @ Lc.T, A)
+    assert lib.tamcmc_host_cholesky(None, 2, Lc.ctypes.data_as(dp)) == accel_mod.capi.E_INVALID
     assert lib.tamcmc_ctx_destroy(None) == 0
 
 
