@@ -316,6 +316,20 @@ struct GlibcRand {
     }
 };
 
+// Box-Muller pair: r8vec_normal_01 writes cos and sin of one angle side by side (random_JB.cpp:120-190), which an
+// optimising compiler turns into ONE sincos() call -- and glibc's sincos differs from its lone sin() / cos() in the last
+// bit about once in 3000 values.  The pair is therefore made by sincos() explicitly, everywhere: the numbers do not
+// depend on the optimisation level this file is built with (the sanitizer build at -O1 used to differ from the product).
+static inline void bm_pair(double r0, double r1, double *c_part, double *s_part)
+{
+    const double PI = 3.141592653589793;
+    double sn, cs;
+    ::sincos(2.0 * PI * r1, &sn, &cs);
+    const double a = std::sqrt(-2.0 * std::log(r0));
+    *c_part = a * cs;
+    *s_part = a * sn;
+}
+
 struct Rng {
     GlibcRand g;
     int saved = 0;       // random_JB.cpp: static int saved; static double y
@@ -324,7 +338,6 @@ struct Rng {
     // r8vec_normal_01(n), random_JB.cpp:22-213
     void normals(int n, double *x)
     {
-        const double PI = 3.141592653589793;
         if (n <= 0) return;
         int x_lo = 1, x_hi = n;
         if (saved == 1) { x[0] = y; saved = 0; x_lo = 2; }
@@ -332,29 +345,21 @@ struct Rng {
         if (cnt == 0) {
         } else if (cnt == 1) {
             const double r0 = uniform(), r1 = uniform();
-            x[x_hi - 1] = std::sqrt(-2.0 * std::log(r0)) * std::cos(2.0 * PI * r1);
-            y = std::sqrt(-2.0 * std::log(r0)) * std::sin(2.0 * PI * r1);
+            bm_pair(r0, r1, &x[x_hi - 1], &y);
             saved = 1;
         } else if (cnt % 2 == 0) {
             const int m = cnt / 2;
             std::vector<double> r(2 * m);
             for (auto &v : r) v = uniform();
-            for (int i = 0; i <= 2 * m - 2; i += 2) {
-                x[x_lo + i - 1] = std::sqrt(-2.0 * std::log(r[i])) * std::cos(2.0 * PI * r[i + 1]);
-                x[x_lo + i] = std::sqrt(-2.0 * std::log(r[i])) * std::sin(2.0 * PI * r[i + 1]);
-            }
+            for (int i = 0; i <= 2 * m - 2; i += 2) bm_pair(r[i], r[i + 1], &x[x_lo + i - 1], &x[x_lo + i]);
         } else {
             x_hi = x_hi - 1;
             const int m = (x_hi - x_lo + 1) / 2 + 1;
             std::vector<double> r(2 * m);
             for (auto &v : r) v = uniform();
-            for (int i = 0; i <= 2 * m - 4; i += 2) {
-                x[x_lo + i - 1] = std::sqrt(-2.0 * std::log(r[i])) * std::cos(2.0 * PI * r[i + 1]);
-                x[x_lo + i] = std::sqrt(-2.0 * std::log(r[i])) * std::sin(2.0 * PI * r[i + 1]);
-            }
+            for (int i = 0; i <= 2 * m - 4; i += 2) bm_pair(r[i], r[i + 1], &x[x_lo + i - 1], &x[x_lo + i]);
             const int i = 2 * m - 2;
-            x[x_lo + i - 1] = std::sqrt(-2.0 * std::log(r[i])) * std::cos(2.0 * PI * r[i + 1]);
-            y = std::sqrt(-2.0 * std::log(r[i])) * std::sin(2.0 * PI * r[i + 1]);
+            bm_pair(r[i], r[i + 1], &x[x_lo + i - 1], &y);
             saved = 1;
         }
     }
@@ -371,19 +376,13 @@ struct Rng {
         static double uni(int32_t v) { return (double)v / 2147483647.0; }
         void fill(double *x) const
         {
-            const double PI = 3.141592653589793;
             if (has_carry_in) x[0] = carry_in;
-            for (int k = 0; k < npairs; k++) {
-                const double a = std::sqrt(-2.0 * std::log(uni(raw[2 * k]))), ang = 2.0 * PI * uni(raw[2 * k + 1]);
-                x[first + 2 * k] = a * std::cos(ang);
-                x[first + 2 * k + 1] = a * std::sin(ang);
-            }
+            for (int k = 0; k < npairs; k++) bm_pair(uni(raw[2 * k]), uni(raw[2 * k + 1]), &x[first + 2 * k], &x[first + 2 * k + 1]);
             if (tail) x[first + 2 * npairs] = tail_x;      // made by draw together with the carried sine (see there)
         }
     };
     void draw(int n, NormalPlan &P)
     {
-        const double PI = 3.141592653589793;
         P.n = n; P.npairs = 0; P.first = 0; P.has_carry_in = false; P.tail = false;
         if (n <= 0) return;
         int cnt = n;
@@ -399,9 +398,7 @@ struct Rng {
             // The last pair: its cosine part is the call's last value, its sine part is kept for the next call.  Both are
             // made HERE, side by side as in r8vec_normal_01 (random_JB.cpp:185-190): a compiler turns the adjacent
             // cos / sin of one angle into one sincos call, whose cosine can differ in the last bit from a lone cos().
-            const double r0 = NormalPlan::uni(P.raw[nr - 2]), r1 = NormalPlan::uni(P.raw[nr - 1]);
-            P.tail_x = std::sqrt(-2.0 * std::log(r0)) * std::cos(2.0 * PI * r1);
-            y = std::sqrt(-2.0 * std::log(r0)) * std::sin(2.0 * PI * r1);
+            bm_pair(NormalPlan::uni(P.raw[nr - 2]), NormalPlan::uni(P.raw[nr - 1]), &P.tail_x, &y);
             saved = 1;
         }
     }
